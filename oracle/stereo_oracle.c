@@ -1,0 +1,574 @@
+/*
+ * stereo_oracle.c -- CPU restatement of the reference's dense-stereo hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle and the timed CPU
+ * baseline.  Nothing in the product (the HIP library or the Python modules in
+ * stereo-matching_amd/) links, loads or calls it; only tests/, the smoke check
+ * and the cpu_baseline leg of bench.py do, and only as the checker.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py compares every function
+ * here against golden vectors produced by running the reference's own Python
+ * source (tests/golden/make_golden.py).  Two third-party calls the reference
+ * makes (cv2.medianBlur, cv2.GaussianBlur) cannot run offline; for those the
+ * oracle follows the documented stand-ins used by the golden generator and
+ * the corresponding fixtures are labelled "*_pin".
+ *
+ * Every function cites the reference lines it restates.  Loop order, operand
+ * order and dtype promotions follow the reference so that float results are
+ * bit-identical to NumPy's where NumPy's own evaluation order is defined
+ * (element-wise ops, sequential cumulative sums, pairwise np.sum).
+ *
+ * Build:  gcc -O2 -fopenmp -ffp-contract=off -fno-fast-math -shared -fPIC
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_OK 0
+#define ORC_EINVAL (-1)
+#define ORC_ENOMEM (-2)
+
+enum { ORC_F32 = 0, ORC_F64 = 1, ORC_U8 = 2 };
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ---------------------------------------------------------------- census */
+
+/* census.py:20-45 -- 8 directions x r=1..radius, (dy*r, dx*r, r). */
+int orc_generate_offsets(int radius, int32_t *out /* [8*radius][3] */) {
+    static const int dirs[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {1, -1}, {-1, 1}, {-1, -1}};
+    if (radius <= 0) return ORC_EINVAL;
+    int n = 0;
+    for (int k = 0; k < 8; ++k)
+        for (int r = 1; r <= radius; ++r) {
+            out[3 * n + 0] = dirs[k][0] * r;
+            out[3 * n + 1] = dirs[k][1] * r;
+            out[3 * n + 2] = r;
+            ++n;
+        }
+    return n;
+}
+
+/* census.py:48-62 -- w = float32(base_weight / 2**(r-1)), the quotient taken in double. */
+void orc_compute_weights(const int32_t *offsets, int n, double base_weight, float *out) {
+    for (int i = 0; i < n; ++i) {
+        int r = offsets[3 * i + 2];
+        double w = base_weight / ldexp(1.0, r - 1);
+        out[i] = (float)w;
+    }
+}
+
+/* census.py:240 -- large_value = float(np.sum(weights)) * 10.0 ; np.sum on float32 is pairwise. */
+static float pairwise_sum_f32(const float *a, int n);
+double orc_large_value(const float *weights, int n) { return (double)pairwise_sum_f32(weights, n) * 10.0; }
+
+/* census.py:65-99 */
+void orc_valid_bounds(int height, int width, const int32_t *offsets, int n, int *bounds /* y0,y1,x0,x1 */) {
+    int y_start = 0, y_end = height, x_start = 0, x_end = width;
+    for (int i = 0; i < n; ++i) {
+        int dy = offsets[3 * i + 0], dx = offsets[3 * i + 1];
+        if (-dy > y_start) y_start = (-dy > 0) ? -dy : 0;
+        if (dy > 0 && height - dy < y_end) y_end = height - dy;
+        if (-dx > x_start) x_start = (-dx > 0) ? -dx : 0;
+        if (dx > 0 && width - dx < x_end) x_end = width - dx;
+    }
+    bounds[0] = y_start; bounds[1] = y_end; bounds[2] = x_start; bounds[3] = x_end;
+}
+
+/* census.py:107-153 -- bits[idx,y,x] = image[y+dy,x+dx] > image[y,x] (strict), 0 where the
+ * neighbour is outside; valid_mask = centre box where every neighbour is inside.
+ * The comparison is made in the caller's dtype. */
+#define DEFINE_CENSUS_BITS(NAME, T)                                                                  \
+    static void NAME(const T *image, int height, int width, const int32_t *offsets, int n,            \
+                     uint8_t *bits, int threads) {                                                    \
+        _Pragma("omp parallel for num_threads(threads) schedule(static)")                             \
+        for (int idx = 0; idx < n; ++idx) {                                                           \
+            int dy = offsets[3 * idx + 0], dx = offsets[3 * idx + 1];                                 \
+            int ys = dy < 0 ? -dy : 0, ye = dy > 0 ? height - dy : height;                            \
+            int xs = dx < 0 ? -dx : 0, xe = dx > 0 ? width - dx : width;                              \
+            if (ys >= ye || xs >= xe) continue;                                                       \
+            uint8_t *plane = bits + (size_t)idx * height * width;                                     \
+            for (int y = ys; y < ye; ++y) {                                                           \
+                const T *row = image + (size_t)y * width;                                             \
+                const T *nrow = image + (size_t)(y + dy) * width;                                     \
+                uint8_t *out = plane + (size_t)y * width;                                             \
+                for (int x = xs; x < xe; ++x) out[x] = (uint8_t)(nrow[x + dx] > row[x]);              \
+            }                                                                                         \
+        }                                                                                             \
+    }
+DEFINE_CENSUS_BITS(census_bits_f32, float)
+DEFINE_CENSUS_BITS(census_bits_f64, double)
+DEFINE_CENSUS_BITS(census_bits_u8, uint8_t)
+
+int orc_census_bits(const void *image, int dtype, int height, int width, const int32_t *offsets, int n,
+                    uint8_t *bits /* [n][H][W], zero-filled here */, uint8_t *valid /* [H][W] */,
+                    int threads) {
+    if (threads < 1) threads = 1;
+    memset(bits, 0, (size_t)n * height * width);
+    memset(valid, 0, (size_t)height * width);
+    int b[4];
+    orc_valid_bounds(height, width, offsets, n, b);
+    if (b[0] < b[1] && b[2] < b[3])
+        for (int y = b[0]; y < b[1]; ++y) memset(valid + (size_t)y * width + b[2], 1, (size_t)(b[3] - b[2]));
+    switch (dtype) {
+        case ORC_F32: census_bits_f32((const float *)image, height, width, offsets, n, bits, threads); break;
+        case ORC_F64: census_bits_f64((const double *)image, height, width, offsets, n, bits, threads); break;
+        case ORC_U8: census_bits_u8((const uint8_t *)image, height, width, offsets, n, bits, threads); break;
+        default: return ORC_EINVAL;
+    }
+    return ORC_OK;
+}
+
+/* census.py:156-202 + :250-267 -- dsi initialised to large, then filled in chunks of
+ * `parallel_chunk` disparities, each chunk a parallel loop over d (at most `parallel_chunk`
+ * threads busy, as in the reference).  cost = sequential float32 adds in offset order. */
+int orc_wct_cost_from_bits(const uint8_t *lbits, const uint8_t *rbits, const uint8_t *lvalid,
+                           const uint8_t *rvalid, const float *weights, int n, int height, int width,
+                           int dmax, float large, float *dsi /* [H][W][D] */, int parallel_chunk,
+                           int threads) {
+    if (dmax <= 0 || parallel_chunk <= 0) return ORC_EINVAL;
+    if (threads < 1) threads = 1;
+    size_t total = (size_t)height * width * dmax;
+    for (size_t i = 0; i < total; ++i) dsi[i] = large;
+    size_t plane = (size_t)height * width;
+    for (int d_start = 0; d_start < dmax; d_start += parallel_chunk) {
+        int d_end = d_start + parallel_chunk < dmax ? d_start + parallel_chunk : dmax;
+        int nt = threads < (d_end - d_start) ? threads : (d_end - d_start);
+        _Pragma("omp parallel for num_threads(nt) schedule(static)")
+        for (int d = d_start; d < d_end; ++d) {
+            for (int y = 0; y < height; ++y) {
+                for (int x = 0; x < width; ++x) {
+                    float *out = dsi + ((size_t)y * width + x) * dmax + d;
+                    if (d > 0 && x < d) { *out = large; continue; }
+                    int xr = x - d;
+                    if (!(lvalid[(size_t)y * width + x] && rvalid[(size_t)y * width + xr])) { *out = large; continue; }
+                    float cost = 0.0f;
+                    const uint8_t *lb = lbits + (size_t)y * width + x;
+                    const uint8_t *rb = rbits + (size_t)y * width + xr;
+                    for (int idx = 0; idx < n; ++idx)
+                        if (lb[idx * plane] != rb[idx * plane]) cost = cost + weights[idx];
+                    *out = cost;
+                }
+            }
+        }
+    }
+    return ORC_OK;
+}
+
+/* census.py:205-269 -- full compute_wct_cost_volume. */
+int orc_wct_cost_volume(const void *left, const void *right, int dtype, int height, int width, int dmax,
+                        int radius, double base_weight, float *dsi, int parallel_chunk, int threads) {
+    if (dmax <= 0 || parallel_chunk <= 0 || radius <= 0) return ORC_EINVAL;
+    int n = 8 * radius;
+    int32_t *offsets = (int32_t *)malloc(sizeof(int32_t) * 3 * n);
+    float *weights = (float *)malloc(sizeof(float) * n);
+    size_t plane = (size_t)height * width;
+    uint8_t *lbits = (uint8_t *)malloc(plane * n), *rbits = (uint8_t *)malloc(plane * n);
+    uint8_t *lvalid = (uint8_t *)malloc(plane), *rvalid = (uint8_t *)malloc(plane);
+    int rc = ORC_ENOMEM;
+    if (offsets && weights && lbits && rbits && lvalid && rvalid) {
+        orc_generate_offsets(radius, offsets);
+        orc_compute_weights(offsets, n, base_weight, weights);
+        float large = (float)orc_large_value(weights, n);
+        rc = orc_census_bits(left, dtype, height, width, offsets, n, lbits, lvalid, threads);
+        if (rc == ORC_OK) rc = orc_census_bits(right, dtype, height, width, offsets, n, rbits, rvalid, threads);
+        if (rc == ORC_OK)
+            rc = orc_wct_cost_from_bits(lbits, rbits, lvalid, rvalid, weights, n, height, width, dmax, large,
+                                        dsi, parallel_chunk, threads);
+    }
+    free(offsets); free(weights); free(lbits); free(rbits); free(lvalid); free(rvalid);
+    return rc;
+}
+
+/* ---------------------------------------------------------- guided filter */
+
+/* guided_filter.py:21-47 -- zero-bordered (H+1,W+1) float64 summed-area table; column
+ * cumulative sums first (sequential over y), then row cumulative sums (sequential over x). */
+int orc_integral_image(const double *image, int height, int width, double *integral) {
+    size_t iw = (size_t)width + 1;
+    double *temp = (double *)malloc(sizeof(double) * (size_t)height * width);
+    if (!temp) return ORC_ENOMEM;
+    memset(integral, 0, sizeof(double) * ((size_t)height + 1) * iw);
+    for (int x = 0; x < width; ++x) {
+        double col_sum = 0.0;
+        for (int y = 0; y < height; ++y) {
+            col_sum = col_sum + image[(size_t)y * width + x];
+            temp[(size_t)y * width + x] = col_sum;
+        }
+    }
+    for (int y = 0; y < height; ++y) {
+        double row_sum = 0.0;
+        for (int x = 0; x < width; ++x) {
+            row_sum = row_sum + temp[(size_t)y * width + x];
+            integral[((size_t)y + 1) * iw + (x + 1)] = row_sum;
+        }
+    }
+    free(temp);
+    return ORC_OK;
+}
+
+/* guided_filter.py:63-86,102-138,155-179 -- box mean over the CLIPPED window:
+ * sum = I[y1+1,x1+1] - I[y0,x1+1] - I[y1+1,x0] + I[y0,x0] (left to right), / area.
+ * The box-sum loop is row-parallel in the reference (prange), the integral image serial. */
+int orc_box_filter_mean(const double *image, int height, int width, int radius, double *out, int threads) {
+    if (height <= 0 || width <= 0 || radius < 0) return ORC_EINVAL;
+    if (threads < 1) threads = 1;
+    size_t iw = (size_t)width + 1;
+    double *integral = (double *)malloc(sizeof(double) * ((size_t)height + 1) * iw);
+    if (!integral) return ORC_ENOMEM;
+    int rc = orc_integral_image(image, height, width, integral);
+    if (rc != ORC_OK) { free(integral); return rc; }
+    _Pragma("omp parallel for num_threads(threads) schedule(static)")
+    for (int y = 0; y < height; ++y) {
+        int y0 = clampi(y - radius, 0, height - 1), y1 = clampi(y + radius, 0, height - 1);
+        for (int x = 0; x < width; ++x) {
+            int x0 = clampi(x - radius, 0, width - 1), x1 = clampi(x + radius, 0, width - 1);
+            double s = integral[((size_t)y1 + 1) * iw + (x1 + 1)] - integral[(size_t)y0 * iw + (x1 + 1)]
+                       - integral[((size_t)y1 + 1) * iw + x0] + integral[(size_t)y0 * iw + x0];
+            double area = (double)((int64_t)(y1 - y0 + 1) * (int64_t)(x1 - x0 + 1));
+            out[(size_t)y * width + x] = s / area;
+        }
+    }
+    free(integral);
+    return ORC_OK;
+}
+
+/* guided_filter.py:182-217 -- per-scene guide statistics (all float64). */
+int orc_guided_prepare(const double *guide, int height, int width, int radius, double *mean_guide,
+                       double *var_g, int threads) {
+    if (radius <= 0) return ORC_EINVAL;
+    size_t n = (size_t)height * width;
+    double *gg = (double *)malloc(sizeof(double) * n);
+    double *mean_gg = (double *)malloc(sizeof(double) * n);
+    if (!gg || !mean_gg) { free(gg); free(mean_gg); return ORC_ENOMEM; }
+    for (size_t i = 0; i < n; ++i) gg[i] = guide[i] * guide[i];
+    int rc = orc_box_filter_mean(guide, height, width, radius, mean_guide, threads);
+    if (rc == ORC_OK) rc = orc_box_filter_mean(gg, height, width, radius, mean_gg, threads);
+    if (rc == ORC_OK)
+        for (size_t i = 0; i < n; ++i) {
+            double v = mean_gg[i] - mean_guide[i] * mean_guide[i];
+            var_g[i] = v > 0.0 ? v : (v != v ? v : 0.0); /* np.maximum(v, 0) propagates NaN */
+        }
+    free(gg); free(mean_gg);
+    return rc;
+}
+
+/* guided_filter.py:220-253 -- one layer.  src is float32 (src.astype(np.float32)); eps is
+ * rounded to float32 and promoted; every intermediate is a float64 full-frame array. */
+int orc_guided_apply(const double *guide, const double *mean_guide, const double *var_g, const float *src,
+                     int height, int width, int radius, double eps, float *out, int threads) {
+    size_t n = (size_t)height * width;
+    double *buf = (double *)malloc(sizeof(double) * n * 6);
+    if (!buf) return ORC_ENOMEM;
+    double *src_d = buf, *gs = buf + n, *mean_src = buf + 2 * n, *mean_gs = buf + 3 * n, *a = buf + 4 * n,
+           *b = buf + 5 * n;
+    const double eps32 = (double)(float)eps;
+    for (size_t i = 0; i < n; ++i) { src_d[i] = (double)src[i]; gs[i] = guide[i] * (double)src[i]; }
+    int rc = orc_box_filter_mean(src_d, height, width, radius, mean_src, threads);
+    if (rc == ORC_OK) rc = orc_box_filter_mean(gs, height, width, radius, mean_gs, threads);
+    if (rc == ORC_OK) {
+        for (size_t i = 0; i < n; ++i) {
+            double cov = mean_gs[i] - mean_guide[i] * mean_src[i];
+            double denom = var_g[i] + eps32;
+            if (denom <= 0.0) denom = eps32;
+            double av = cov / denom;
+            a[i] = av;
+            b[i] = mean_src[i] - av * mean_guide[i];
+        }
+        /* reuse src_d/gs as mean_a/mean_b */
+        rc = orc_box_filter_mean(a, height, width, radius, src_d, threads);
+        if (rc == ORC_OK) rc = orc_box_filter_mean(b, height, width, radius, gs, threads);
+        if (rc == ORC_OK)
+            for (size_t i = 0; i < n; ++i) out[i] = (float)(src_d[i] * guide[i] + gs[i]);
+    }
+    free(buf);
+    return rc;
+}
+
+/* ----------------------------------------------------------------- np.sum */
+
+/* NumPy's pairwise float32 reduction for a contiguous run (what np.sum does on a fresh
+ * contiguous array): n < 8 sequential; n <= 128 eight interleaved partial sums combined as
+ * ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) then the tail; larger n split recursively. */
+static float pairwise_sum_f32(const float *a, int n) {
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        float r[8];
+        int i;
+        for (i = 0; i < 8; ++i) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return pairwise_sum_f32(a, n2) + pairwise_sum_f32(a + n2, n - n2);
+    }
+}
+
+/* ----------------------------------------------------------- other filters */
+
+static int reflect101(int i, int n) { /* np.pad(mode="reflect") == BORDER_REFLECT_101 */
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * (n - 1) - i;
+    }
+    return i;
+}
+
+/* filters.py:24-39 -- float32 meshgrid, exp of a float32 array, normalised by float(np.sum). */
+int orc_gaussian_kernel(int radius, double sigma, float *kernel /* [(2r+1)^2] */) {
+    if (radius <= 0 || !(sigma > 0)) return ORC_EINVAL;
+    int size = 2 * radius + 1;
+    /* 2.0 * sigma * sigma is a Python float; dividing a float32 array by it keeps float32 */
+    float denom = (float)(2.0 * sigma * sigma);
+    for (int yy = -radius; yy <= radius; ++yy)
+        for (int xx = -radius; xx <= radius; ++xx) {
+            float fx = (float)xx, fy = (float)yy;
+            float arg = -(fx * fx + fy * fy) / denom;
+            kernel[(yy + radius) * size + (xx + radius)] = expf(arg);
+        }
+    float s = pairwise_sum_f32(kernel, size * size);
+    double ksum = (double)s;
+    if (ksum <= 0.0) return ORC_EINVAL;
+    float fs = (float)ksum;
+    for (int i = 0; i < size * size; ++i) kernel[i] = kernel[i] / fs;
+    return ORC_OK;
+}
+
+int orc_radius_from_sigma(double sigma) { /* filters.py:42-47 */
+    int r = (int)ceil(3.0 * sigma);
+    return r > 1 ? r : 1;
+}
+
+/* filters.py:191-204 -- per-pixel sum(window * kernel) in float32, reflect padding. */
+int orc_gaussian_filter(const float *image, int height, int width, double sigma, float *out, int threads) {
+    if (!(sigma > 0)) return ORC_EINVAL;
+    if (threads < 1) threads = 1;
+    int radius = orc_radius_from_sigma(sigma), size = 2 * radius + 1;
+    if (radius >= height || radius >= width) return ORC_EINVAL; /* np.pad reflect needs pad < dim */
+    float *kernel = (float *)malloc(sizeof(float) * size * size);
+    if (!kernel) return ORC_ENOMEM;
+    int rc = orc_gaussian_kernel(radius, sigma, kernel);
+    if (rc != ORC_OK) { free(kernel); return rc; }
+    _Pragma("omp parallel for num_threads(threads) schedule(static)")
+    for (int y = 0; y < height; ++y) {
+        float prod[1024];
+        for (int x = 0; x < width; ++x) {
+            int k = 0;
+            for (int dy = -radius; dy <= radius; ++dy) {
+                int yy = reflect101(y + dy, height);
+                for (int dx = -radius; dx <= radius; ++dx) {
+                    int xx = reflect101(x + dx, width);
+                    prod[k] = image[(size_t)yy * width + xx] * kernel[k];
+                    ++k;
+                }
+            }
+            out[(size_t)y * width + x] = pairwise_sum_f32(prod, k);
+        }
+    }
+    free(kernel);
+    return ORC_OK;
+}
+
+/* filters.py:279-310 -- same sigma for space and range; float32 throughout. */
+int orc_bilateral_filter(const float *image, int height, int width, double sigma, float *out, int threads) {
+    if (!(sigma > 0)) return ORC_EINVAL;
+    if (threads < 1) threads = 1;
+    int radius = orc_radius_from_sigma(sigma), size = 2 * radius + 1;
+    if (radius >= height || radius >= width) return ORC_EINVAL;
+    float *kernel = (float *)malloc(sizeof(float) * size * size);
+    if (!kernel) return ORC_ENOMEM;
+    int rc = orc_gaussian_kernel(radius, sigma, kernel);
+    if (rc != ORC_OK) { free(kernel); return rc; }
+    const float denom = (float)(2.0 * (double)(sigma * sigma));
+    _Pragma("omp parallel for num_threads(threads) schedule(static)")
+    for (int y = 0; y < height; ++y) {
+        float wts[1024], prod[1024];
+        for (int x = 0; x < width; ++x) {
+            float center = image[(size_t)y * width + x];
+            int k = 0;
+            for (int dy = -radius; dy <= radius; ++dy) {
+                int yy = reflect101(y + dy, height);
+                for (int dx = -radius; dx <= radius; ++dx) {
+                    int xx = reflect101(x + dx, width);
+                    float v = image[(size_t)yy * width + xx];
+                    float diff = v - center;
+                    float rw = expf(-(diff * diff) / denom);
+                    wts[k] = kernel[k] * rw;
+                    prod[k] = v * wts[k];
+                    ++k;
+                }
+            }
+            double weight_sum = (double)pairwise_sum_f32(wts, k);
+            if (weight_sum <= 0.0) out[(size_t)y * width + x] = center;
+            else out[(size_t)y * width + x] = pairwise_sum_f32(prod, k) / (float)weight_sum;
+        }
+    }
+    free(kernel);
+    return ORC_OK;
+}
+
+static int cmp_f32(const void *a, const void *b) {
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* filters.py:95-136 -- exact median of the (2r+1)^2 window, edge ("nearest") padding.
+ * The scipy, vectorized and naive methods agree for finite input (odd window). */
+int orc_median_filter(const float *image, int height, int width, int radius, float *out, int threads) {
+    if (radius <= 0) return ORC_EINVAL;
+    if (threads < 1) threads = 1;
+    int size = 2 * radius + 1, cnt = size * size;
+    if (cnt > 4096) return ORC_EINVAL;
+    _Pragma("omp parallel for num_threads(threads) schedule(static)")
+    for (int y = 0; y < height; ++y) {
+        float win[4096];
+        for (int x = 0; x < width; ++x) {
+            int k = 0;
+            for (int dy = -radius; dy <= radius; ++dy) {
+                int yy = clampi(y + dy, 0, height - 1);
+                for (int dx = -radius; dx <= radius; ++dx) win[k++] = image[(size_t)yy * width + clampi(x + dx, 0, width - 1)];
+            }
+            qsort(win, cnt, sizeof(float), cmp_f32);
+            out[(size_t)y * width + x] = win[cnt / 2];
+        }
+    }
+    return ORC_OK;
+}
+
+/* filters.py:139-180 -- the "opencv" median: min-max quantise to uint8 (np.rint = half to
+ * even), exact uint8 median with replicate border (what cv2.medianBlur computes), rescale in
+ * float32.  Returns ORC_EINVAL for non-finite input (the reference raises ValueError). */
+int orc_median_filter_u8q(const float *image, int height, int width, int radius, float *out, int threads) {
+    if (radius <= 0) return ORC_EINVAL;
+    if (threads < 1) threads = 1;
+    size_t n = (size_t)height * width;
+    float lo = image[0], hi = image[0];
+    for (size_t i = 0; i < n; ++i) {
+        float v = image[i];
+        if (!isfinite(v)) return ORC_EINVAL;
+        if (v < lo) lo = v;
+        if (v > hi) hi = v;
+    }
+    double min_value = (double)lo, max_value = (double)hi;
+    if (max_value == min_value) {
+        for (size_t i = 0; i < n; ++i) out[i] = (float)min_value;
+        return ORC_OK;
+    }
+    /* scale / min_value are Python floats combined with float32 arrays: the array ops stay
+     * float32 with the scalar rounded to float32 */
+    float scale = (float)(255.0 / (max_value - min_value));
+    float inv_scale = (float)((max_value - min_value) / 255.0);
+    float minf = (float)min_value;
+    uint8_t *q = (uint8_t *)malloc(n);
+    if (!q) return ORC_ENOMEM;
+    for (size_t i = 0; i < n; ++i) {
+        float s = (image[i] - minf) * scale;
+        s = s < 0.0f ? 0.0f : (s > 255.0f ? 255.0f : s);
+        q[i] = (uint8_t)nearbyintf(s);
+    }
+    int size = 2 * radius + 1, cnt = size * size;
+    _Pragma("omp parallel for num_threads(threads) schedule(static)")
+    for (int y = 0; y < height; ++y) {
+        int hist[256];
+        for (int x = 0; x < width; ++x) {
+            memset(hist, 0, sizeof(hist));
+            for (int dy = -radius; dy <= radius; ++dy) {
+                int yy = clampi(y + dy, 0, height - 1);
+                for (int dx = -radius; dx <= radius; ++dx) hist[q[(size_t)yy * width + clampi(x + dx, 0, width - 1)]]++;
+            }
+            int acc = 0, m = 0;
+            for (m = 0; m < 256; ++m) { acc += hist[m]; if (acc > cnt / 2) break; }
+            out[(size_t)y * width + x] = (float)m * inv_scale + minf;
+        }
+    }
+    free(q);
+    return ORC_OK;
+}
+
+/* -------------------------------------------------------------------- WTA */
+
+/* stereo.py:167-170 -- strict '<' (NaN never wins, ties keep the lower disparity). */
+void orc_wta_update(const float *filtered, size_t n, int d, float *min_cost, int32_t *disparity) {
+    for (size_t i = 0; i < n; ++i)
+        if (filtered[i] < min_cost[i]) { min_cost[i] = filtered[i]; disparity[i] = d; }
+}
+
+enum { ORC_FILTER_GUIDED = 0, ORC_FILTER_MEDIAN = 1, ORC_FILTER_MEDIAN_U8Q = 2, ORC_FILTER_GAUSSIAN = 3,
+       ORC_FILTER_BILATERAL = 4 };
+
+/* stereo.py:94-174 -- per layer: strided gather of dsi[:,:,d], filter, WTA.  If
+ * `layers_out` is non-NULL every filtered layer is also stored there ([D][H][W]) for the
+ * gap-aware comparisons in the tests. */
+int orc_aggregate_and_wta(const float *dsi, const double *guide, int height, int width, int dmax,
+                          int filter_kind, int radius, double eps_or_sigma, int32_t *disparity,
+                          float *min_cost, float *layers_out, int threads) {
+    size_t n = (size_t)height * width;
+    float *layer = (float *)malloc(sizeof(float) * n), *filtered = (float *)malloc(sizeof(float) * n);
+    double *mean_guide = NULL, *var_g = NULL;
+    int rc = (layer && filtered) ? ORC_OK : ORC_ENOMEM;
+    for (size_t i = 0; i < n && rc == ORC_OK; ++i) { min_cost[i] = INFINITY; disparity[i] = 0; }
+    if (rc == ORC_OK && filter_kind == ORC_FILTER_GUIDED) {
+        mean_guide = (double *)malloc(sizeof(double) * n);
+        var_g = (double *)malloc(sizeof(double) * n);
+        rc = (mean_guide && var_g) ? orc_guided_prepare(guide, height, width, radius, mean_guide, var_g, threads)
+                                   : ORC_ENOMEM;
+    }
+    for (int d = 0; d < dmax && rc == ORC_OK; ++d) {
+        for (size_t i = 0; i < n; ++i) layer[i] = dsi[i * dmax + d];
+        switch (filter_kind) {
+            case ORC_FILTER_GUIDED:
+                rc = orc_guided_apply(guide, mean_guide, var_g, layer, height, width, radius, eps_or_sigma,
+                                      filtered, threads);
+                break;
+            case ORC_FILTER_MEDIAN: rc = orc_median_filter(layer, height, width, radius, filtered, threads); break;
+            case ORC_FILTER_MEDIAN_U8Q: rc = orc_median_filter_u8q(layer, height, width, radius, filtered, threads); break;
+            case ORC_FILTER_GAUSSIAN: rc = orc_gaussian_filter(layer, height, width, eps_or_sigma, filtered, threads); break;
+            case ORC_FILTER_BILATERAL: rc = orc_bilateral_filter(layer, height, width, eps_or_sigma, filtered, threads); break;
+            default: rc = ORC_EINVAL;
+        }
+        if (rc != ORC_OK) break;
+        if (layers_out) memcpy(layers_out + (size_t)d * n, filtered, sizeof(float) * n);
+        orc_wta_update(filtered, n, d, min_cost, disparity);
+    }
+    free(layer); free(filtered); free(mean_guide); free(var_g);
+    return rc;
+}
+
+/* stereo.py:177-245 -- compute_disparity on float32 gray images. */
+int orc_compute_disparity(const float *left, const float *right, int height, int width, int dmax,
+                          int wct_radius, double base_weight, int filter_kind, int radius,
+                          double eps_or_sigma, int32_t *disparity, float *min_cost, int threads) {
+    size_t n = (size_t)height * width;
+    float *dsi = (float *)malloc(sizeof(float) * n * (size_t)dmax);
+    double *guide = (double *)malloc(sizeof(double) * n);
+    int rc = (dsi && guide) ? ORC_OK : ORC_ENOMEM;
+    if (rc == ORC_OK) {
+        for (size_t i = 0; i < n; ++i) guide[i] = (double)left[i];
+        rc = orc_wct_cost_volume(left, right, ORC_F32, height, width, dmax, wct_radius, base_weight, dsi, 8, threads);
+    }
+    if (rc == ORC_OK)
+        rc = orc_aggregate_and_wta(dsi, guide, height, width, dmax, filter_kind, radius, eps_or_sigma, disparity,
+                                   min_cost, NULL, threads);
+    free(dsi); free(guide);
+    return rc;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
