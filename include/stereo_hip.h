@@ -1,0 +1,144 @@
+/*
+ * stereo_hip.h -- C ABI of libstereo_hip.so, the MI355X (gfx950) implementation of the
+ * dense-stereo hot path: weighted-census cost -> per-disparity edge-aware filter -> WTA.
+ *
+ * The reference is pure Python; its "operator API" is the set of module-level functions in
+ * census.py / guided_filter.py / filters.py / stereo.py.  Each entry point below names the
+ * reference function it replaces.  All arrays are row-major and contiguous; sizes are in
+ * elements.  Functions return 0 on success or a negative STEREO_E* code;
+ * stereo_hip_last_error() returns a thread-local description of the last failure.
+ *
+ * *_host entry points take HOST pointers, stage data through device memory they allocate
+ * themselves and block until the result is in the caller's output buffer.
+ * *_dev entry points take DEVICE pointers and a HIP stream (passed as void*, i.e. a
+ * hipStream_t), allocate nothing and return after enqueueing.
+ */
+#ifndef STEREO_HIP_H
+#define STEREO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEREO_OK 0
+#define STEREO_EINVAL (-1)       /* argument violates the reference's own validation */
+#define STEREO_EUNSUPPORTED (-2) /* valid for the reference, not implemented on the GPU path */
+#define STEREO_EHIP (-3)         /* HIP runtime error (no device, launch failure, ...) */
+#define STEREO_ENOMEM (-4)       /* device or host allocation failed */
+#define STEREO_ENONFINITE (-5)   /* non-finite input where the reference raises ValueError */
+
+/* element types accepted for gray images (the census compares in the caller's dtype) */
+#define STEREO_DT_F32 0
+#define STEREO_DT_F64 1
+#define STEREO_DT_U8 2
+
+/* aggregation filter (stereo.py:136-165) */
+#define STEREO_FILTER_GUIDED 0
+#define STEREO_FILTER_MEDIAN 1     /* exact median of the float window: scipy/vectorized/naive */
+#define STEREO_FILTER_MEDIAN_U8Q 2 /* "opencv": uint8 min-max quantised median (filters.py:139-180) */
+#define STEREO_FILTER_GAUSSIAN 3
+#define STEREO_FILTER_BILATERAL 4
+
+/* Parameters of stereo.aggregate_and_wta / stereo.compute_disparity (stereo.py:94-245). */
+typedef struct StereoParams {
+    int32_t wct_radius;     /* census radius, 1..8 on the GPU path (reference default 4) */
+    double base_weight;     /* weight of the r=1 ring (reference default 8.0) */
+    int32_t filter_kind;    /* STEREO_FILTER_* */
+    int32_t guided_radius;  /* guided-filter window radius (default 3) */
+    double guided_eps;      /* guided-filter regulariser; rounded to float32 as the reference does */
+    int32_t median_radius;  /* median window radius (default 3) */
+    double gaussian_sigma;  /* default 1.0; window radius = max(ceil(3 sigma), 1) */
+    double bilateral_sigma; /* default 1.0; same sigma for space and range */
+} StereoParams;
+
+/* ---- library state -------------------------------------------------------------------- */
+int stereo_hip_init(int device);             /* select the device used by *_host calls */
+int stereo_hip_device_count(int *count);
+const char *stereo_hip_last_error(void);
+const char *stereo_hip_version(void);
+
+/* ---- census.py ------------------------------------------------------------------------- */
+/* census.generate_offsets (census.py:20-45): out[8*radius][3] = (dy, dx, r). Host only. */
+int stereo_generate_offsets(int radius, int32_t *out);
+/* census.compute_weights (census.py:48-62): float32(base_weight / 2**(r-1)). Host only. */
+int stereo_compute_weights(const int32_t *offsets, int n, double base_weight, float *out);
+/* large_value of census.py:240 for (radius, base_weight). Host only. */
+int stereo_large_value(int radius, double base_weight, float *out);
+/* census.compute_wct_cost_volume (census.py:205-269): out_dsi[H][W][dmax] float32. */
+int stereo_wct_cost_volume_host(const void *left, const void *right, int dtype, int height, int width,
+                                int dmax, int radius, double base_weight, float *out_dsi);
+
+/* ---- guided_filter.py ------------------------------------------------------------------ */
+/* _integral_image_numba / README's integral_image (guided_filter.py:21-47): out[(H+1)][(W+1)]. */
+int stereo_integral_image_host(const double *image, int height, int width, double *out);
+/* box_filter_mean (guided_filter.py:141-179): clipped-window mean, radius >= 0. */
+int stereo_box_filter_mean_host(const double *image, int height, int width, int radius, double *out);
+/* box_filter_mean_with_indices (guided_filter.py:155-179): caller-supplied window bounds
+ * y0/y1[H], x0/x1[W] (inclusive) and per-pixel area[H][W]. */
+int stereo_box_filter_mean_indexed_host(const double *image, int height, int width, const int32_t *y0,
+                                        const int32_t *y1, const int32_t *x0, const int32_t *x1,
+                                        const double *area, double *out);
+/* prepare_guided_filter (guided_filter.py:182-217): mean_guide, mean_gg, var_g, each [H][W]. */
+int stereo_guided_prepare_host(const double *guide, int height, int width, int radius, double *mean_guide,
+                               double *mean_gg, double *var_g);
+/* guided_filter (guided_filter.py:256-275) = prepare_guided_filter + guided_filter_with_precompute. */
+int stereo_guided_filter_host(const double *guide, const float *src, int height, int width, int radius,
+                              double eps, float *out);
+
+/* ---- filters.py ------------------------------------------------------------------------ */
+/* median_filter (filters.py:227-256). mode: STEREO_FILTER_MEDIAN or STEREO_FILTER_MEDIAN_U8Q. */
+int stereo_median_filter_host(const float *image, int height, int width, int radius, int mode, float *out);
+/* median_filter(method="opencv") on a uint8 image: no rescaling (filters.py:158-161). */
+int stereo_median_filter_u8_host(const uint8_t *image, int height, int width, int radius, float *out);
+/* gaussian_filter (filters.py:259-276); numerics follow the reference's naive path (:191-204). */
+int stereo_gaussian_filter_host(const float *image, int height, int width, double sigma, float *out);
+/* bilateral_filter (filters.py:279-310). */
+int stereo_bilateral_filter_host(const float *image, int height, int width, double sigma, float *out);
+
+/* ---- stereo.py ------------------------------------------------------------------------- */
+/* aggregate_and_wta (stereo.py:94-174) on a materialised cost volume dsi[H][W][D].
+ * guide_dtype: STEREO_DT_F32 or STEREO_DT_F64. Layers d in [d_begin, d_end) are aggregated. */
+int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dtype, int height, int width,
+                              int dmax, const StereoParams *params, int d_begin, int d_end,
+                              int32_t *out_disparity, float *out_min_cost);
+/* compute_disparity (stereo.py:177-245).  float32 / uint8 images with the guided filter
+ * (radius <= 4) take the fused kernel: the cost volume is never materialised.  Other
+ * combinations build the cost layers on the device and filter them one at a time.
+ * Disparities d in [d_begin, d_end) are searched. */
+int stereo_compute_disparity_host(const void *left, const void *right, int dtype, int height, int width,
+                                  int dmax, const StereoParams *params, int d_begin, int d_end,
+                                  int32_t *out_disparity, float *out_min_cost);
+
+/* ---- device-pointer path (bench, multi-GPU sharding) ------------------------------------ */
+/* Scratch the fused path needs for one (H, W) frame, in bytes. */
+int stereo_fused_workspace_bytes(int height, int width, const StereoParams *params, size_t *bytes);
+/* Fused compute_disparity over d in [d_begin, d_end) on float32 device images.  Writes one
+ * packed key per pixel: (order-preserving uint32 image of the float32 min cost) << 32 | d, so
+ * that an unsigned 64-bit MIN over keys of different disparity shards is the reference's
+ * "lowest cost, ties to the lowest disparity" rule (stereo.py:167-170). */
+int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int height, int width, int dmax,
+                                 const StereoParams *params, int d_begin, int d_end, void *d_workspace,
+                                 size_t workspace_bytes, uint64_t *d_keys, void *stream);
+/* keys[i] = min(keys[i], other[i]) -- local merge of two disparity shards. */
+int stereo_merge_keys_dev(uint64_t *d_keys, const uint64_t *d_other, size_t n, void *stream);
+/* Map keys to a signed-int64-comparable form and back (torch/RCCL reduce int64, not uint64). */
+int stereo_keys_to_i64_dev(const uint64_t *d_keys, int64_t *d_out, size_t n, void *stream);
+int stereo_keys_from_i64_dev(const int64_t *d_in, uint64_t *d_keys, size_t n, void *stream);
+/* Unpack keys into int32 disparity and float32 min cost (never-updated pixels: 0 and +inf). */
+int stereo_unpack_keys_dev(const uint64_t *d_keys, size_t n, int32_t *d_disparity, float *d_min_cost,
+                           void *stream);
+
+/* Timing of the dominant (fused) kernel with HIP events recorded on the launch stream, for
+ * bench.py's roofline figure; no counterpart in the reference.  stereo_profile_begin creates up
+ * to max_launches event pairs and arms recording; stereo_profile_end synchronises, returns the
+ * summed kernel time in milliseconds and the number of launches seen, and disarms. */
+int stereo_profile_begin(int max_launches);
+int stereo_profile_end(double *total_ms, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEREO_HIP_H */

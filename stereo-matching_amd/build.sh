@@ -1,0 +1,22 @@
+#!/bin/bash
+# Build libstereo_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+OUT="$HERE/libstereo_hip.so"
+SRCS=("$HERE"/csrc/*.hip)
+mkdir -p "$HERE/csrc/obj"
+OBJS=()
+pids=()
+for src in "${SRCS[@]}"; do
+  obj="$HERE/csrc/obj/$(basename "${src%.hip}").o"
+  OBJS+=("$obj")
+  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$HERE/csrc/common.hpp" -nt "$obj" || "$HERE/csrc/census_dev.hpp" -nt "$obj" || "$HERE/../include/stereo_hip.h" -nt "$obj" ]]; then
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$HERE/../include" -I"$HERE/csrc" \
+      -Wall -Wno-unused-function ${EXTRA_HIPCC_FLAGS:-} -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJS[@]}"
+echo "built $OUT"

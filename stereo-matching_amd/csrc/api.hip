@@ -1,0 +1,581 @@
+// C ABI of libstereo_hip.so (see include/stereo_hip.h).
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace shp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? STEREO_ENOMEM : STEREO_EHIP;
+}
+
+// Optional timing of the dominant kernel: events are created by stereo_profile_begin (never in
+// the launch path) and recorded on the launch stream around every fused-kernel launch.
+struct ProfileState {
+    std::vector<hipEvent_t> start, stop;
+    int used = 0;
+    bool enabled = false;
+};
+static ProfileState g_prof;
+
+static int check_params(const StereoParams *p) {
+    if (!p) { set_error("params is NULL"); return STEREO_EINVAL; }
+    switch (p->filter_kind) {
+        case STEREO_FILTER_GUIDED:
+            if (p->guided_radius <= 0) { set_error("guided radius must be a positive integer"); return STEREO_EINVAL; }
+            if (!(p->guided_eps > 0)) { set_error("guided eps must be positive"); return STEREO_EINVAL; }
+            break;
+        case STEREO_FILTER_MEDIAN:
+        case STEREO_FILTER_MEDIAN_U8Q:
+            if (p->median_radius <= 0) { set_error("median radius must be a positive integer"); return STEREO_EINVAL; }
+            break;
+        case STEREO_FILTER_GAUSSIAN:
+            if (!(p->gaussian_sigma > 0)) { set_error("gaussian sigma must be positive"); return STEREO_EINVAL; }
+            break;
+        case STEREO_FILTER_BILATERAL:
+            if (!(p->bilateral_sigma > 0)) { set_error("bilateral sigma must be positive"); return STEREO_EINVAL; }
+            break;
+        default: set_error("unknown filter kind %d", p->filter_kind); return STEREO_EINVAL;
+    }
+    return STEREO_OK;
+}
+
+static int check_image_dims(int H, int W) {
+    if (H <= 0 || W <= 0) { set_error("image must be non-empty, got %d x %d", H, W); return STEREO_EINVAL; }
+    if (H > 65535) { set_error("image height %d exceeds 65535", H); return STEREO_EUNSUPPORTED; }
+    return STEREO_OK;
+}
+
+static size_t dtype_size(int dt) { return dt == STEREO_DT_F64 ? 8 : (dt == STEREO_DT_U8 ? 1 : 4); }
+
+// layout of the fused workspace
+struct FusedWs {
+    size_t words_bytes, plane_f64;
+    size_t off_lw, off_rw, off_mean, off_invden, total;
+};
+static FusedWs fused_ws_layout(int H, int W, int wct_radius) {
+    FusedWs w;
+    size_t n = (size_t)H * W;
+    w.words_bytes = align_up(n * (wct_radius > 4 ? 8 : 4), 256);
+    w.plane_f64 = align_up(n * 8, 256);
+    w.off_lw = 0;
+    w.off_rw = w.off_lw + w.words_bytes;
+    w.off_mean = w.off_rw + w.words_bytes;
+    w.off_invden = w.off_mean + w.plane_f64;
+    w.total = w.off_invden + w.plane_f64;
+    return w;
+}
+
+// Fused compute_disparity on device float32 images; keys receive the packed result.
+static int fused_disparity_dev(const float *d_left, const float *d_right, int H, int W, int dmax,
+                               const StereoParams *p, int d_begin, int d_end, void *ws, size_t ws_bytes,
+                               uint64_t *d_keys, float *d_q_out, hipStream_t s) {
+    SHP_TRY(check_params(p));
+    SHP_TRY(check_image_dims(H, W));
+    if (dmax <= 0) { set_error("dmax must be a positive integer"); return STEREO_EINVAL; }
+    if (d_begin < 0 || d_end > dmax || d_begin > d_end) {
+        set_error("disparity range [%d, %d) outside [0, %d)", d_begin, d_end, dmax);
+        return STEREO_EINVAL;
+    }
+    CensusCfg cfg;
+    SHP_TRY(make_census_cfg(p->wct_radius, p->base_weight, &cfg));
+    FusedWs L = fused_ws_layout(H, W, p->wct_radius);
+    if (ws_bytes < L.total) { set_error("workspace too small: %zu < %zu", ws_bytes, L.total); return STEREO_EINVAL; }
+    unsigned char *base = static_cast<unsigned char *>(ws);
+    void *lw = base + L.off_lw, *rw = base + L.off_rw;
+    double *mean = reinterpret_cast<double *>(base + L.off_mean);
+    double *invden = reinterpret_cast<double *>(base + L.off_invden);
+    SHP_TRY(launch_census_pack(d_left, STEREO_DT_F32, H, W, p->wct_radius, lw, s));
+    SHP_TRY(launch_census_pack(d_right, STEREO_DT_F32, H, W, p->wct_radius, rw, s));
+    if (p->filter_kind == STEREO_FILTER_GUIDED) {
+        if (!fused_guided_supported(p->guided_radius)) {
+            set_error("fused guided path supports radius 1..4, got %d", p->guided_radius);
+            return STEREO_EUNSUPPORTED;
+        }
+        SHP_TRY(launch_guide_stats(d_left, STEREO_DT_F32, H, W, p->guided_radius, p->guided_eps, mean, invden,
+                                   nullptr, s));
+        if (d_begin == d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
+        const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();
+        if (prof) SHP_HIP(hipEventRecord(g_prof.start[g_prof.used], s));
+        int rc = launch_fused_guided(lw, rw, &cfg, nullptr, d_left, STEREO_DT_F32, mean, invden, H, W, dmax,
+                                     p->guided_radius, d_begin, d_end, d_keys, d_q_out, 0, s);
+        if (prof) {
+            SHP_HIP(hipEventRecord(g_prof.stop[g_prof.used], s));
+            ++g_prof.used;
+        }
+        return rc;
+    }
+    set_error("filter kind %d is not implemented on the fused path yet", p->filter_kind);
+    return STEREO_EUNSUPPORTED;
+}
+
+// stereo.py:145-170 one layer at a time on a (D', H, W) device volume whose layer k is
+// disparity d_begin + k.  Used for every filter / parameter combination the fused kernels do
+// not cover.  Everything is enqueued on `s`; the only host sync is the final flag read.
+static int layered_aggregate_dev(const float *d_layers, const void *d_guide, int guide_dtype, int H, int W,
+                                 const StereoParams *p, int d_begin, int d_end, uint64_t *d_keys, hipStream_t s) {
+    const size_t n = (size_t)H * W;
+    SHP_TRY(launch_fill_keys(d_keys, n, s));
+    if (d_begin >= d_end) return STEREO_OK;
+    DevBuf out, ws, kern, mm, q, sc;
+    SHP_TRY(out.alloc(n * 4));
+    int radius = 0;
+    switch (p->filter_kind) {
+        case STEREO_FILTER_GUIDED:
+            SHP_TRY(ws.alloc(layered_guided_ws_bytes(H, W)));
+            SHP_TRY(layered_guided_prepare(d_guide, guide_dtype, H, W, p->guided_radius, ws.p, s));
+            break;
+        case STEREO_FILTER_MEDIAN: break;
+        case STEREO_FILTER_MEDIAN_U8Q:
+            SHP_TRY(mm.alloc(16)); SHP_TRY(q.alloc(n)); SHP_TRY(sc.alloc(16));
+            SHP_HIP(hipMemsetAsync(mm.p, 0, 16, s));
+            break;
+        case STEREO_FILTER_GAUSSIAN:
+        case STEREO_FILTER_BILATERAL: {
+            double sigma = p->filter_kind == STEREO_FILTER_GAUSSIAN ? p->gaussian_sigma : p->bilateral_sigma;
+            radius = radius_from_sigma(sigma);
+            if (radius > 32) { set_error("filter radius %d > 32 is not supported on the GPU path", radius); return STEREO_EUNSUPPORTED; }
+            std::vector<float> k((size_t)(2 * radius + 1) * (2 * radius + 1));
+            gaussian_kernel_host(radius, sigma, k.data());
+            SHP_TRY(kern.alloc(k.size() * 4));
+            SHP_HIP(hipMemcpyAsync(kern.p, k.data(), k.size() * 4, hipMemcpyHostToDevice, s));
+            SHP_HIP(hipStreamSynchronize(s));  // k goes out of scope below
+            break;
+        }
+        default: set_error("unknown filter kind"); return STEREO_EINVAL;
+    }
+    for (int d = d_begin; d < d_end; ++d) {
+        const float *layer = d_layers + (size_t)(d - d_begin) * n;
+        switch (p->filter_kind) {
+            case STEREO_FILTER_GUIDED:
+                SHP_TRY(layered_guided_apply(layer, H, W, p->guided_radius, p->guided_eps, ws.p, out.as<float>(), s));
+                break;
+            case STEREO_FILTER_MEDIAN: SHP_TRY(launch_median_f32(layer, H, W, p->median_radius, out.as<float>(), s)); break;
+            case STEREO_FILTER_MEDIAN_U8Q:
+                SHP_TRY(launch_median_u8q(layer, H, W, p->median_radius, mm.as<uint32_t>(), q.as<uint8_t>(), sc.as<float>(),
+                                          out.as<float>(), s));
+                break;
+            case STEREO_FILTER_GAUSSIAN: SHP_TRY(launch_gaussian(layer, H, W, radius, kern.as<float>(), out.as<float>(), s)); break;
+            case STEREO_FILTER_BILATERAL:
+                SHP_TRY(launch_bilateral(layer, H, W, radius, kern.as<float>(), p->bilateral_sigma, out.as<float>(), s));
+                break;
+        }
+        SHP_TRY(launch_wta_update(out.as<float>(), n, d, d_keys, s));
+    }
+    if (p->filter_kind == STEREO_FILTER_MEDIAN_U8Q) {
+        uint32_t h[4] = {0, 0, 0, 0};
+        SHP_HIP(hipMemcpyAsync(h, mm.p, 16, hipMemcpyDeviceToHost, s));
+        SHP_HIP(hipStreamSynchronize(s));
+        if (h[2]) { set_error("the opencv median needs finite values"); return STEREO_ENONFINITE; }
+    }
+    SHP_HIP(hipStreamSynchronize(s));
+    return STEREO_OK;
+}
+
+static int finish_keys_to_host(uint64_t *d_keys, size_t n, int32_t *out_disp, float *out_cost) {
+    DevBuf disp, cost;
+    SHP_TRY(disp.alloc(n * 4)); SHP_TRY(cost.alloc(n * 4));
+    SHP_TRY(launch_unpack_keys(d_keys, n, disp.as<int32_t>(), cost.as<float>(), nullptr));
+    SHP_HIP(hipMemcpy(out_disp, disp.p, n * 4, hipMemcpyDeviceToHost));
+    SHP_HIP(hipMemcpy(out_cost, cost.p, n * 4, hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+
+}  // namespace shp
+
+using namespace shp;
+
+extern "C" {
+
+const char *stereo_hip_last_error(void) { return g_err; }
+const char *stereo_hip_version(void) { return "stereo_hip 0.1 (gfx950)"; }
+
+int stereo_hip_device_count(int *count) {
+    if (!count) return STEREO_EINVAL;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return STEREO_OK;
+}
+
+int stereo_hip_init(int device) {
+    int n = 0;
+    SHP_HIP(hipGetDeviceCount(&n));
+    if (n <= 0) { set_error("no HIP device is visible"); return STEREO_EHIP; }
+    if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return STEREO_EINVAL; }
+    SHP_HIP(hipSetDevice(device));
+    return STEREO_OK;
+}
+
+int stereo_generate_offsets(int radius, int32_t *out) {
+    static const int dirs[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {1, -1}, {-1, 1}, {-1, -1}};
+    if (radius <= 0 || !out) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
+    int n = 0;
+    for (int k = 0; k < 8; ++k)
+        for (int r = 1; r <= radius; ++r, ++n) {
+            out[3 * n + 0] = dirs[k][0] * r;
+            out[3 * n + 1] = dirs[k][1] * r;
+            out[3 * n + 2] = r;
+        }
+    return STEREO_OK;
+}
+
+int stereo_compute_weights(const int32_t *offsets, int n, double base_weight, float *out) {
+    if (n < 0 || (n > 0 && (!offsets || !out))) { set_error("bad offsets"); return STEREO_EINVAL; }
+    for (int i = 0; i < n; ++i) out[i] = (float)(base_weight / std::ldexp(1.0, offsets[3 * i + 2] - 1));
+    return STEREO_OK;
+}
+
+int stereo_large_value(int radius, double base_weight, float *out) {
+    CensusCfg cfg;
+    SHP_TRY(make_census_cfg(radius, base_weight, &cfg));
+    *out = cfg.large;
+    return STEREO_OK;
+}
+
+int stereo_wct_cost_volume_host(const void *left, const void *right, int dtype, int H, int W, int dmax, int radius,
+                                double base_weight, float *out_dsi) {
+    if (dmax <= 0) { set_error("dmax must be a positive integer"); return STEREO_EINVAL; }
+    SHP_TRY(check_image_dims(H, W));
+    if (dtype != STEREO_DT_F32 && dtype != STEREO_DT_F64 && dtype != STEREO_DT_U8) {
+        set_error("unsupported image dtype %d", dtype);
+        return STEREO_EINVAL;
+    }
+    CensusCfg cfg;
+    SHP_TRY(make_census_cfg(radius, base_weight, &cfg));
+    size_t n = (size_t)H * W, img_bytes = n * dtype_size(dtype), word_bytes = n * (cfg.word64 ? 8 : 4);
+    DevBuf dl, dr, lw, rw, dsi;
+    SHP_TRY(dl.alloc(img_bytes)); SHP_TRY(dr.alloc(img_bytes));
+    SHP_TRY(lw.alloc(word_bytes)); SHP_TRY(rw.alloc(word_bytes));
+    SHP_TRY(dsi.alloc(n * (size_t)dmax * sizeof(float)));
+    SHP_HIP(hipMemcpy(dl.p, left, img_bytes, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dr.p, right, img_bytes, hipMemcpyHostToDevice));
+    SHP_TRY(launch_census_pack(dl.p, dtype, H, W, radius, lw.p, nullptr));
+    SHP_TRY(launch_census_pack(dr.p, dtype, H, W, radius, rw.p, nullptr));
+    SHP_TRY(launch_dsi(lw.p, rw.p, H, W, dmax, cfg, dsi.as<float>(), nullptr));
+    SHP_HIP(hipMemcpy(out_dsi, dsi.p, n * (size_t)dmax * sizeof(float), hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+
+int stereo_fused_workspace_bytes(int H, int W, const StereoParams *p, size_t *bytes) {
+    if (!p || !bytes) { set_error("NULL argument"); return STEREO_EINVAL; }
+    SHP_TRY(check_image_dims(H, W));
+    *bytes = fused_ws_layout(H, W, p->wct_radius).total;
+    return STEREO_OK;
+}
+
+int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int H, int W, int dmax,
+                                 const StereoParams *p, int d_begin, int d_end, void *ws, size_t ws_bytes,
+                                 uint64_t *d_keys, void *stream) {
+    return fused_disparity_dev(d_left, d_right, H, W, dmax, p, d_begin, d_end, ws, ws_bytes, d_keys, nullptr,
+                               static_cast<hipStream_t>(stream));
+}
+
+int stereo_profile_begin(int max_launches) {
+    if (max_launches < 0) { set_error("max_launches must be >= 0"); return STEREO_EINVAL; }
+    while ((int)g_prof.start.size() < max_launches) {
+        hipEvent_t a, b;
+        SHP_HIP(hipEventCreate(&a));
+        SHP_HIP(hipEventCreate(&b));
+        g_prof.start.push_back(a);
+        g_prof.stop.push_back(b);
+    }
+    g_prof.used = 0;
+    g_prof.enabled = max_launches > 0;
+    return STEREO_OK;
+}
+
+int stereo_profile_end(double *total_ms, int *launches) {
+    double total = 0.0;
+    for (int i = 0; i < g_prof.used; ++i) {
+        SHP_HIP(hipEventSynchronize(g_prof.stop[i]));
+        float ms = 0.f;
+        SHP_HIP(hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]));
+        total += (double)ms;
+    }
+    if (total_ms) *total_ms = total;
+    if (launches) *launches = g_prof.used;
+    g_prof.enabled = false;
+    g_prof.used = 0;
+    return STEREO_OK;
+}
+
+int stereo_merge_keys_dev(uint64_t *d_keys, const uint64_t *d_other, size_t n, void *stream) {
+    return launch_merge_keys(d_keys, d_other, n, static_cast<hipStream_t>(stream));
+}
+int stereo_keys_to_i64_dev(const uint64_t *d_keys, int64_t *d_out, size_t n, void *stream) {
+    return launch_keys_to_i64(d_keys, d_out, n, static_cast<hipStream_t>(stream));
+}
+int stereo_keys_from_i64_dev(const int64_t *d_in, uint64_t *d_keys, size_t n, void *stream) {
+    return launch_keys_from_i64(d_in, d_keys, n, static_cast<hipStream_t>(stream));
+}
+int stereo_unpack_keys_dev(const uint64_t *d_keys, size_t n, int32_t *d_disp, float *d_cost, void *stream) {
+    return launch_unpack_keys(d_keys, n, d_disp, d_cost, static_cast<hipStream_t>(stream));
+}
+
+int stereo_compute_disparity_host(const void *left, const void *right, int dtype, int H, int W, int dmax,
+                                  const StereoParams *p, int d_begin, int d_end, int32_t *out_disp,
+                                  float *out_cost) {
+    SHP_TRY(check_params(p));
+    SHP_TRY(check_image_dims(H, W));
+    if (dmax <= 0) { set_error("dmax must be a positive integer"); return STEREO_EINVAL; }
+    if (d_begin < 0 || d_end > dmax || d_begin > d_end) { set_error("bad disparity range"); return STEREO_EINVAL; }
+    if (dtype != STEREO_DT_F32 && dtype != STEREO_DT_F64 && dtype != STEREO_DT_U8) {
+        set_error("unsupported image dtype %d", dtype);
+        return STEREO_EINVAL;
+    }
+    CensusCfg cfg;
+    SHP_TRY(make_census_cfg(p->wct_radius, p->base_weight, &cfg));
+    const size_t n = (size_t)H * W;
+    DevBuf keys;
+    SHP_TRY(keys.alloc(n * 8));
+    const bool fused = p->filter_kind == STEREO_FILTER_GUIDED && fused_guided_supported(p->guided_radius) &&
+                       dtype != STEREO_DT_F64;
+    if (fused) {
+        std::vector<float> lf, rf;
+        const float *hl = static_cast<const float *>(left), *hr = static_cast<const float *>(right);
+        if (dtype == STEREO_DT_U8) {  // uint8 -> float32 is exact and order preserving
+            lf.resize(n); rf.resize(n);
+            const uint8_t *l8 = static_cast<const uint8_t *>(left), *r8 = static_cast<const uint8_t *>(right);
+            for (size_t i = 0; i < n; ++i) { lf[i] = (float)l8[i]; rf[i] = (float)r8[i]; }
+            hl = lf.data(); hr = rf.data();
+        }
+        FusedWs L = fused_ws_layout(H, W, p->wct_radius);
+        DevBuf dl, dr, ws;
+        SHP_TRY(dl.alloc(n * 4)); SHP_TRY(dr.alloc(n * 4)); SHP_TRY(ws.alloc(L.total));
+        SHP_HIP(hipMemcpy(dl.p, hl, n * 4, hipMemcpyHostToDevice));
+        SHP_HIP(hipMemcpy(dr.p, hr, n * 4, hipMemcpyHostToDevice));
+        SHP_TRY(fused_disparity_dev(dl.as<float>(), dr.as<float>(), H, W, dmax, p, d_begin, d_end, ws.p, L.total,
+                                    keys.as<uint64_t>(), nullptr, nullptr));
+        return finish_keys_to_host(keys.as<uint64_t>(), n, out_disp, out_cost);
+    }
+    // general path: cost layers on the device, then one filter launch chain per layer
+    const size_t img_bytes = n * dtype_size(dtype), word_bytes = n * (cfg.word64 ? 8 : 4);
+    DevBuf dl, dr, lw, rw, layers, guide;
+    SHP_TRY(dl.alloc(img_bytes)); SHP_TRY(dr.alloc(img_bytes));
+    SHP_TRY(lw.alloc(word_bytes)); SHP_TRY(rw.alloc(word_bytes));
+    SHP_TRY(layers.alloc(n * (size_t)(d_end - d_begin) * 4));
+    SHP_HIP(hipMemcpy(dl.p, left, img_bytes, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dr.p, right, img_bytes, hipMemcpyHostToDevice));
+    SHP_TRY(launch_census_pack(dl.p, dtype, H, W, p->wct_radius, lw.p, nullptr));
+    SHP_TRY(launch_census_pack(dr.p, dtype, H, W, p->wct_radius, rw.p, nullptr));
+    SHP_TRY(launch_dsi_layers(lw.p, rw.p, H, W, d_begin, d_end, cfg, layers.as<float>(), nullptr));
+    const void *g = dl.p;
+    int gdt = dtype;
+    if (dtype == STEREO_DT_U8) {  // the guide is the left image as float64 (guided_filter.py:202)
+        std::vector<float> lf(n);
+        const uint8_t *l8 = static_cast<const uint8_t *>(left);
+        for (size_t i = 0; i < n; ++i) lf[i] = (float)l8[i];
+        SHP_TRY(guide.alloc(n * 4));
+        SHP_HIP(hipMemcpy(guide.p, lf.data(), n * 4, hipMemcpyHostToDevice));
+        g = guide.p;
+        gdt = STEREO_DT_F32;
+    }
+    SHP_TRY(layered_aggregate_dev(layers.as<float>(), g, gdt, H, W, p, d_begin, d_end, keys.as<uint64_t>(), nullptr));
+    return finish_keys_to_host(keys.as<uint64_t>(), n, out_disp, out_cost);
+}
+
+int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dtype, int H, int W, int dmax,
+                              const StereoParams *p, int d_begin, int d_end, int32_t *out_disp, float *out_cost) {
+    SHP_TRY(check_params(p));
+    SHP_TRY(check_image_dims(H, W));
+    if (dmax <= 0) { set_error("dsi must have at least one disparity layer"); return STEREO_EINVAL; }
+    if (d_begin < 0 || d_end > dmax || d_begin > d_end) { set_error("bad disparity range"); return STEREO_EINVAL; }
+    if (guide_dtype != STEREO_DT_F32 && guide_dtype != STEREO_DT_F64) {
+        set_error("guide dtype must be float32 or float64");
+        return STEREO_EINVAL;
+    }
+    size_t n = (size_t)H * W;
+    DevBuf ddsi, dg, mean, invden, keys, layers;
+    SHP_TRY(ddsi.alloc(n * (size_t)dmax * 4));
+    SHP_TRY(dg.alloc(n * dtype_size(guide_dtype)));
+    SHP_TRY(keys.alloc(n * 8));
+    SHP_HIP(hipMemcpy(ddsi.p, dsi, n * (size_t)dmax * 4, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dg.p, guide, n * dtype_size(guide_dtype), hipMemcpyHostToDevice));
+    if (p->filter_kind == STEREO_FILTER_GUIDED && fused_guided_supported(p->guided_radius)) {
+        SHP_TRY(mean.alloc(n * 8)); SHP_TRY(invden.alloc(n * 8));
+        SHP_TRY(launch_guide_stats(dg.p, guide_dtype, H, W, p->guided_radius, p->guided_eps, mean.as<double>(),
+                                   invden.as<double>(), nullptr, nullptr));
+        if (d_begin == d_end) SHP_TRY(launch_fill_keys(keys.as<uint64_t>(), n, nullptr));
+        else
+            SHP_TRY(launch_fused_guided(nullptr, nullptr, nullptr, ddsi.as<float>(), dg.p, guide_dtype,
+                                        mean.as<double>(), invden.as<double>(), H, W, dmax, p->guided_radius,
+                                        d_begin, d_end, keys.as<uint64_t>(), nullptr, 0, nullptr));
+    } else {
+        SHP_TRY(layers.alloc(n * (size_t)dmax * 4));
+        SHP_TRY(launch_dsi_to_layers(ddsi.as<float>(), n, dmax, layers.as<float>(), nullptr));
+        ddsi.release();
+        SHP_TRY(layered_aggregate_dev(layers.as<float>() + (size_t)d_begin * n, dg.p, guide_dtype, H, W, p, d_begin,
+                                      d_end, keys.as<uint64_t>(), nullptr));
+    }
+    return finish_keys_to_host(keys.as<uint64_t>(), n, out_disp, out_cost);
+}
+
+int stereo_guided_filter_host(const double *guide, const float *src, int H, int W, int radius, double eps,
+                              float *out) {
+    SHP_TRY(check_image_dims(H, W));
+    if (radius <= 0) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
+    if (!(eps > 0)) { set_error("eps must be positive"); return STEREO_EINVAL; }
+    size_t n = (size_t)H * W;
+    DevBuf dg, ds, q;
+    SHP_TRY(dg.alloc(n * 8)); SHP_TRY(ds.alloc(n * 4)); SHP_TRY(q.alloc(n * 4));
+    SHP_HIP(hipMemcpy(dg.p, guide, n * 8, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(ds.p, src, n * 4, hipMemcpyHostToDevice));
+    if (fused_guided_supported(radius)) {
+        DevBuf mean, invden, keys;
+        SHP_TRY(mean.alloc(n * 8)); SHP_TRY(invden.alloc(n * 8)); SHP_TRY(keys.alloc(n * 8));
+        SHP_TRY(launch_guide_stats(dg.p, STEREO_DT_F64, H, W, radius, eps, mean.as<double>(), invden.as<double>(),
+                                   nullptr, nullptr));
+        SHP_TRY(launch_fused_guided(nullptr, nullptr, nullptr, ds.as<float>(), dg.p, STEREO_DT_F64, mean.as<double>(),
+                                    invden.as<double>(), H, W, 1, radius, 0, 1, keys.as<uint64_t>(), q.as<float>(), 0,
+                                    nullptr));
+    } else {
+        DevBuf ws;
+        SHP_TRY(ws.alloc(layered_guided_ws_bytes(H, W)));
+        SHP_TRY(layered_guided_prepare(dg.p, STEREO_DT_F64, H, W, radius, ws.p, nullptr));
+        SHP_TRY(layered_guided_apply(ds.as<float>(), H, W, radius, eps, ws.p, q.as<float>(), nullptr));
+    }
+    SHP_HIP(hipMemcpy(out, q.p, n * 4, hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+
+int stereo_guided_prepare_host(const double *guide, int H, int W, int radius, double *mean_guide, double *mean_gg,
+                               double *var_g) {
+    SHP_TRY(check_image_dims(H, W));
+    if (radius <= 0) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
+    size_t n = (size_t)H * W;
+    DevBuf dg, ws;
+    SHP_TRY(dg.alloc(n * 8)); SHP_TRY(ws.alloc(layered_guided_ws_bytes(H, W)));
+    SHP_HIP(hipMemcpy(dg.p, guide, n * 8, hipMemcpyHostToDevice));
+    SHP_TRY(layered_guided_prepare(dg.p, STEREO_DT_F64, H, W, radius, ws.p, nullptr));
+    double *g64, *mg, *mgg, *var;
+    layered_guided_planes(ws.p, H, W, &g64, &mg, &mgg, &var);
+    SHP_HIP(hipMemcpy(mean_guide, mg, n * 8, hipMemcpyDeviceToHost));
+    SHP_HIP(hipMemcpy(mean_gg, mgg, n * 8, hipMemcpyDeviceToHost));
+    SHP_HIP(hipMemcpy(var_g, var, n * 8, hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+
+int stereo_integral_image_host(const double *image, int H, int W, double *out) {
+    SHP_TRY(check_image_dims(H, W));
+    size_t n = (size_t)H * W, ni = ((size_t)H + 1) * ((size_t)W + 1);
+    DevBuf di, tmp, integ;
+    SHP_TRY(di.alloc(n * 8)); SHP_TRY(tmp.alloc(n * 8)); SHP_TRY(integ.alloc(ni * 8));
+    SHP_HIP(hipMemcpy(di.p, image, n * 8, hipMemcpyHostToDevice));
+    SHP_TRY(launch_integral(di.p, STEREO_DT_F64, H, W, tmp.as<double>(), integ.as<double>(), nullptr));
+    SHP_HIP(hipMemcpy(out, integ.p, ni * 8, hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+
+int stereo_box_filter_mean_host(const double *image, int H, int W, int radius, double *out) {
+    SHP_TRY(check_image_dims(H, W));
+    if (radius < 0) { set_error("radius must be a non-negative integer"); return STEREO_EINVAL; }
+    size_t n = (size_t)H * W, ni = ((size_t)H + 1) * ((size_t)W + 1);
+    DevBuf di, tmp, integ, dout;
+    SHP_TRY(di.alloc(n * 8)); SHP_TRY(tmp.alloc(n * 8)); SHP_TRY(integ.alloc(ni * 8)); SHP_TRY(dout.alloc(n * 8));
+    SHP_HIP(hipMemcpy(di.p, image, n * 8, hipMemcpyHostToDevice));
+    SHP_TRY(launch_box_mean(di.p, STEREO_DT_F64, H, W, radius, tmp.as<double>(), integ.as<double>(), dout.as<double>(),
+                            nullptr));
+    SHP_HIP(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+
+int stereo_box_filter_mean_indexed_host(const double *image, int H, int W, const int32_t *y0, const int32_t *y1,
+                                        const int32_t *x0, const int32_t *x1, const double *area, double *out) {
+    SHP_TRY(check_image_dims(H, W));
+    for (int y = 0; y < H; ++y)
+        if (y0[y] < 0 || y1[y] >= H || y0[y] > H) { set_error("row window out of range"); return STEREO_EINVAL; }
+    for (int x = 0; x < W; ++x)
+        if (x0[x] < 0 || x1[x] >= W || x0[x] > W) { set_error("column window out of range"); return STEREO_EINVAL; }
+    size_t n = (size_t)H * W, ni = ((size_t)H + 1) * ((size_t)W + 1);
+    DevBuf di, tmp, integ, dout, dy0, dy1, dx0, dx1, dar;
+    SHP_TRY(di.alloc(n * 8)); SHP_TRY(tmp.alloc(n * 8)); SHP_TRY(integ.alloc(ni * 8)); SHP_TRY(dout.alloc(n * 8));
+    SHP_TRY(dy0.alloc(H * 4)); SHP_TRY(dy1.alloc(H * 4)); SHP_TRY(dx0.alloc(W * 4)); SHP_TRY(dx1.alloc(W * 4));
+    SHP_TRY(dar.alloc(n * 8));
+    SHP_HIP(hipMemcpy(di.p, image, n * 8, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dy0.p, y0, H * 4, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dy1.p, y1, H * 4, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dx0.p, x0, W * 4, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dx1.p, x1, W * 4, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dar.p, area, n * 8, hipMemcpyHostToDevice));
+    SHP_TRY(launch_integral(di.p, STEREO_DT_F64, H, W, tmp.as<double>(), integ.as<double>(), nullptr));
+    SHP_TRY(launch_box_from_integral(integ.as<double>(), H, W, dy0.as<int>(), dy1.as<int>(), dx0.as<int>(),
+                                     dx1.as<int>(), dar.as<double>(), 0, dout.as<double>(), nullptr));
+    SHP_HIP(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+
+int stereo_median_filter_host(const float *image, int H, int W, int radius, int mode, float *out) {
+    SHP_TRY(check_image_dims(H, W));
+    if (radius <= 0) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
+    size_t n = (size_t)H * W;
+    DevBuf di, dout;
+    SHP_TRY(di.alloc(n * 4)); SHP_TRY(dout.alloc(n * 4));
+    SHP_HIP(hipMemcpy(di.p, image, n * 4, hipMemcpyHostToDevice));
+    if (mode == STEREO_FILTER_MEDIAN) {
+        SHP_TRY(launch_median_f32(di.as<float>(), H, W, radius, dout.as<float>(), nullptr));
+    } else if (mode == STEREO_FILTER_MEDIAN_U8Q) {
+        DevBuf mm, q, sc;
+        SHP_TRY(mm.alloc(16)); SHP_TRY(q.alloc(n)); SHP_TRY(sc.alloc(16));
+        SHP_HIP(hipMemset(mm.p, 0, 16));
+        SHP_TRY(launch_median_u8q(di.as<float>(), H, W, radius, mm.as<uint32_t>(), q.as<uint8_t>(), sc.as<float>(),
+                                  dout.as<float>(), nullptr));
+        uint32_t h[4];
+        SHP_HIP(hipMemcpy(h, mm.p, 16, hipMemcpyDeviceToHost));
+        if (h[2]) { set_error("the opencv median needs finite values"); return STEREO_ENONFINITE; }
+    } else { set_error("unknown median mode %d", mode); return STEREO_EINVAL; }
+    SHP_HIP(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+
+int stereo_median_filter_u8_host(const uint8_t *image, int H, int W, int radius, float *out) {
+    SHP_TRY(check_image_dims(H, W));
+    if (radius <= 0) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
+    size_t n = (size_t)H * W;
+    DevBuf di, dout;
+    SHP_TRY(di.alloc(n)); SHP_TRY(dout.alloc(n * 4));
+    SHP_HIP(hipMemcpy(di.p, image, n, hipMemcpyHostToDevice));
+    SHP_TRY(launch_median_u8(di.as<uint8_t>(), H, W, radius, 1.0f, 0.0f, 0, dout.as<float>(), nullptr));
+    SHP_HIP(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+
+static int gauss_like_host(const float *image, int H, int W, double sigma, float *out, bool bilateral) {
+    SHP_TRY(check_image_dims(H, W));
+    if (!(sigma > 0)) { set_error("sigma must be positive"); return STEREO_EINVAL; }
+    int r = radius_from_sigma(sigma);
+    if (r > 32) { set_error("filter radius %d > 32 is not supported on the GPU path", r); return STEREO_EUNSUPPORTED; }
+    size_t n = (size_t)H * W;
+    std::vector<float> k((size_t)(2 * r + 1) * (2 * r + 1));
+    gaussian_kernel_host(r, sigma, k.data());
+    DevBuf di, dout, dk;
+    SHP_TRY(di.alloc(n * 4)); SHP_TRY(dout.alloc(n * 4)); SHP_TRY(dk.alloc(k.size() * 4));
+    SHP_HIP(hipMemcpy(di.p, image, n * 4, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dk.p, k.data(), k.size() * 4, hipMemcpyHostToDevice));
+    if (bilateral) SHP_TRY(launch_bilateral(di.as<float>(), H, W, r, dk.as<float>(), sigma, dout.as<float>(), nullptr));
+    else SHP_TRY(launch_gaussian(di.as<float>(), H, W, r, dk.as<float>(), dout.as<float>(), nullptr));
+    SHP_HIP(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+int stereo_gaussian_filter_host(const float *image, int H, int W, double sigma, float *out) {
+    return gauss_like_host(image, H, W, sigma, out, false);
+}
+int stereo_bilateral_filter_host(const float *image, int H, int W, double sigma, float *out) {
+    return gauss_like_host(image, H, W, sigma, out, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+// Weighted census transform: per-pixel packed census words and the (H, W, D) cost volume.
+//
+// Reference semantics (census.py:107-153, :156-202): bit(idx) = img[y+dy, x+dx] > img[y, x]
+// (strict, caller's dtype, 0 when the neighbour is outside the image); the cost of (y, x, d) is
+// the weight-sum over offsets whose left/right bits differ, or `large` when x < d or either
+// centre pixel is within `radius` of an image border.
+//
+// Packing: offsets come in 8 directions x radius rings with weight base/2^(r-1).  Direction k
+// owns a 4-bit (radius <= 4) or 8-bit (radius <= 8) field whose bit for ring r has place value
+// 2^(field_bits - r), so the field of L^R read as an integer IS that direction's weighted
+// Hamming cost in units of base/2^(field_bits-1).  The whole cost is then the sum of the
+// fields: one v_dot8_u32_u4 (or two v_dot4_u32_u8) per evaluation.
+#include "census_dev.hpp"
+
+namespace shp {
+
+// ---- host-side census configuration ---------------------------------------------------------
+
+// NumPy's pairwise float32 sum for n <= 128 (what np.sum(weights) evaluates, census.py:240).
+static float np_sum_f32(const float *a, int n) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    float r[8];
+    int i;
+    for (i = 0; i < 8; ++i) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+int make_census_cfg(int radius, double base_weight, CensusCfg *cfg) {
+    if (radius <= 0) {
+        set_error("radius must be a positive integer");
+        return STEREO_EINVAL;
+    }
+    if (radius > 8) {
+        set_error("census radius %d > 8 is not supported by the GPU path", radius);
+        return STEREO_EUNSUPPORTED;
+    }
+    cfg->radius = radius;
+    cfg->word64 = radius > 4;
+    float all[64];
+    for (int r = 1; r <= 8; ++r) cfg->w[r - 1] = (float)(base_weight / std::ldexp(1.0, r - 1));
+    for (int k = 0; k < 8; ++k)
+        for (int r = 1; r <= radius; ++r) all[k * radius + (r - 1)] = cfg->w[r - 1];
+    cfg->large = (float)((double)np_sum_f32(all, 8 * radius) * 10.0);
+    const int field_bits = cfg->word64 ? 8 : 4;
+    cfg->unit = cfg->w[field_bits - 1];  // base / 2^(field_bits-1), value of the lowest bit
+    // The reference adds float32 weights one by one.  Every partial sum is m * unit with
+    // m <= 8 * (2^field_bits - 1); all are exact if mantissa_bits(base) + bits(m_max) <= 24.
+    float bf = (float)base_weight;
+    int exact = 0;
+    if (std::isfinite(bf) && bf != 0.f && std::fabs(cfg->unit) >= 1.17549435e-38f) {
+        uint32_t bits;
+        memcpy(&bits, &bf, 4);
+        uint32_t mant = (bits & 0x7fffffu) | 0x800000u;
+        int tz = __builtin_ctz(mant);
+        int sig_bits = 24 - tz;
+        // `large` = 10 * sum(weights) must be an exact multiple of the unit as well:
+        // 10 * 120 < 2^11 (4-bit fields), 10 * 2040 < 2^15 (8-bit fields)
+        int m_bits = cfg->word64 ? 15 : 11;
+        exact = (sig_bits + m_bits <= 24);
+    }
+    cfg->exact = exact;
+    return STEREO_OK;
+}
+
+// ---- census packing ---------------------------------------------------------------------------
+
+constexpr int CP_TW = 64;  // tile width  (one wavefront per row)
+constexpr int CP_TH = 16;  // tile height
+
+template <typename T, typename WordT>
+__global__ __launch_bounds__(256) void census_pack_kernel(const T *__restrict__ img, int H, int W, int R,
+                                                          WordT *__restrict__ words) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *tile = reinterpret_cast<T *>(smem_raw);
+    const int LW = CP_TW + 2 * R, LH = CP_TH + 2 * R;
+    const int x0 = blockIdx.x * CP_TW, y0 = blockIdx.y * CP_TH;
+    // stage the tile and its halo; out-of-image cells are never compared (masked below)
+    for (int i = threadIdx.x; i < LW * LH; i += blockDim.x) {
+        int ly = i / LW, lx = i - ly * LW;
+        int gy = y0 - R + ly, gx = x0 - R + lx;
+        T v = T(0);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img[(size_t)gy * W + gx];
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int FB = (sizeof(WordT) == 8) ? 8 : 4;
+    const int dys[8] = {1, -1, 0, 0, 1, 1, -1, -1};
+    const int dxs[8] = {0, 0, 1, -1, 1, -1, 1, -1};
+    const int lx = threadIdx.x & 63;
+    for (int ly = threadIdx.x >> 6; ly < CP_TH; ly += 4) {
+        int gy = y0 + ly, gx = x0 + lx;
+        if (gy >= H || gx >= W) continue;
+        T c = tile[(ly + R) * LW + (lx + R)];
+        WordT word = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            for (int r = 1; r <= R; ++r) {
+                int ny = gy + dys[k] * r, nx = gx + dxs[k] * r;
+                bool inside = (ny >= 0) & (ny < H) & (nx >= 0) & (nx < W);
+                T v = tile[(ly + R + dys[k] * r) * LW + (lx + R + dxs[k] * r)];
+                WordT bit = (inside && (v > c)) ? WordT(1) : WordT(0);
+                word |= bit << (FB * k + (FB - r));
+            }
+        }
+        words[(size_t)gy * W + gx] = word;
+    }
+}
+
+template <typename T>
+static int launch_census_pack_t(const T *img, int H, int W, int R, void *words, hipStream_t s) {
+    dim3 grid(ceil_div(W, CP_TW), ceil_div(H, CP_TH));
+    size_t smem = (size_t)(CP_TW + 2 * R) * (CP_TH + 2 * R) * sizeof(T);
+    if (R <= 4)
+        hipLaunchKernelGGL((census_pack_kernel<T, uint32_t>), grid, dim3(256), smem, s, img, H, W, R,
+                           static_cast<uint32_t *>(words));
+    else
+        hipLaunchKernelGGL((census_pack_kernel<T, uint64_t>), grid, dim3(256), smem, s, img, H, W, R,
+                           static_cast<uint64_t *>(words));
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+int launch_census_pack(const void *d_img, int dtype, int H, int W, int radius, void *d_words, hipStream_t s) {
+    if (H <= 0 || W <= 0) return STEREO_OK;
+    switch (dtype) {
+        case STEREO_DT_F32: return launch_census_pack_t(static_cast<const float *>(d_img), H, W, radius, d_words, s);
+        case STEREO_DT_F64: return launch_census_pack_t(static_cast<const double *>(d_img), H, W, radius, d_words, s);
+        case STEREO_DT_U8: return launch_census_pack_t(static_cast<const uint8_t *>(d_img), H, W, radius, d_words, s);
+        default: set_error("unsupported image dtype %d", dtype); return STEREO_EINVAL;
+    }
+}
+
+// ---- materialised cost volume, D innermost (census.py:250) -----------------------------------
+
+constexpr int DSI_XB = 64;  // pixels of one row handled by a block
+
+template <typename WordT>
+__global__ __launch_bounds__(256) void dsi_kernel(const WordT *__restrict__ lw, const WordT *__restrict__ rw,
+                                                  int H, int W, int D, CensusCfg cfg, float *__restrict__ dsi) {
+    const int y = blockIdx.y;
+    const int x0 = blockIdx.x * DSI_XB;
+    const int npx = min(DSI_XB, W - x0);
+    const int R = cfg.radius;
+    const bool row_ok = (y >= R) && (y < H - R);
+    const WordT *lrow = lw + (size_t)y * W;
+    const WordT *rrow = rw + (size_t)y * W;
+    float *out = dsi + ((size_t)y * W + x0) * D;
+    const int total = npx * D;  // <= 64 * D
+    // walk the flat (pixel, d) index with d fastest so that stores are fully coalesced
+    const int step_q = 256 / D, step_r = 256 % D;
+    int j = threadIdx.x;
+    int xl = j / D, d = j - xl * D;
+    for (; j < total; j += 256) {
+        int x = x0 + xl;
+        float c = cfg.large;
+        if (row_ok && x >= R && x < W - R && x - d >= R) c = pair_cost<WordT>(lrow[x], rrow[x - d], cfg);
+        out[j] = c;
+        xl += step_q;
+        d += step_r;
+        if (d >= D) { d -= D; ++xl; }
+    }
+}
+
+int launch_dsi(const void *d_lw, const void *d_rw, int H, int W, int dmax, const CensusCfg &cfg, float *d_dsi,
+               hipStream_t s) {
+    if (H <= 0 || W <= 0) return STEREO_OK;
+    if ((long long)DSI_XB * dmax > 0x7fffffffLL) {
+        set_error("dmax %d too large", dmax);
+        return STEREO_EUNSUPPORTED;
+    }
+    dim3 grid(ceil_div(W, DSI_XB), H);
+    if (cfg.word64)
+        hipLaunchKernelGGL(dsi_kernel<uint64_t>, grid, dim3(256), 0, s, static_cast<const uint64_t *>(d_lw),
+                           static_cast<const uint64_t *>(d_rw), H, W, dmax, cfg, d_dsi);
+    else
+        hipLaunchKernelGGL(dsi_kernel<uint32_t>, grid, dim3(256), 0, s, static_cast<const uint32_t *>(d_lw),
+                           static_cast<const uint32_t *>(d_rw), H, W, dmax, cfg, d_dsi);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+// Same costs in (D, H, W) order: the layout the layer-at-a-time aggregation reads.
+template <typename WordT>
+__global__ __launch_bounds__(256) void dsi_layers_kernel(const WordT *__restrict__ lw, const WordT *__restrict__ rw,
+                                                         int H, int W, int d_begin, CensusCfg cfg,
+                                                         float *__restrict__ layers) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int d = d_begin + blockIdx.z;
+    if (x >= W) return;
+    const int R = cfg.radius;
+    float c = cfg.large;
+    if (y >= R && y < H - R && x >= R && x < W - R && x - d >= R)
+        c = pair_cost<WordT>(lw[(size_t)y * W + x], rw[(size_t)y * W + x - d], cfg);
+    layers[((size_t)blockIdx.z * H + y) * W + x] = c;
+}
+
+// layers[k] = cost layer d_begin + k, k in [0, d_end - d_begin)
+int launch_dsi_layers(const void *d_lw, const void *d_rw, int H, int W, int d_begin, int d_end, const CensusCfg &cfg,
+                      float *d_layers, hipStream_t s) {
+    if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
+    for (int d0 = d_begin; d0 < d_end; d0 += 32768) {
+        int nd = min(32768, d_end - d0);
+        dim3 grid(ceil_div(W, 256), H, nd);
+        float *out = d_layers + (size_t)(d0 - d_begin) * H * W;
+        if (cfg.word64)
+            hipLaunchKernelGGL(dsi_layers_kernel<uint64_t>, grid, dim3(256), 0, s, static_cast<const uint64_t *>(d_lw),
+                               static_cast<const uint64_t *>(d_rw), H, W, d0, cfg, out);
+        else
+            hipLaunchKernelGGL(dsi_layers_kernel<uint32_t>, grid, dim3(256), 0, s, static_cast<const uint32_t *>(d_lw),
+                               static_cast<const uint32_t *>(d_rw), H, W, d0, cfg, out);
+        SHP_LAUNCH_CHECK();
+    }
+    return STEREO_OK;
+}
+
+// ---- packed-key utilities ----------------------------------------------------------------------
+
+__global__ void unpack_keys_kernel(const uint64_t *__restrict__ keys, size_t n, int32_t *__restrict__ disp,
+                                   float *__restrict__ cost) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t k = keys[i];
+        disp[i] = (int32_t)(uint32_t)k;
+        cost[i] = ordered_to_f32((uint32_t)(k >> 32));
+    }
+}
+__global__ void merge_keys_kernel(uint64_t *__restrict__ keys, const uint64_t *__restrict__ other, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t a = keys[i], b = other[i];
+        keys[i] = b < a ? b : a;
+    }
+}
+__global__ void fill_keys_kernel(uint64_t *__restrict__ keys, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        keys[i] = SHP_KEY_INIT;
+}
+// uint64 order -> int64 order: flip the top bit (and back).
+__global__ void keys_flip_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = in[i] ^ 0x8000000000000000ull;
+}
+
+static inline int ew_grid(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+int launch_unpack_keys(const uint64_t *keys, size_t n, int32_t *disp, float *cost, hipStream_t s) {
+    if (n == 0) return STEREO_OK;
+    hipLaunchKernelGGL(unpack_keys_kernel, dim3(ew_grid(n)), dim3(256), 0, s, keys, n, disp, cost);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+int launch_merge_keys(uint64_t *keys, const uint64_t *other, size_t n, hipStream_t s) {
+    if (n == 0) return STEREO_OK;
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(ew_grid(n)), dim3(256), 0, s, keys, other, n);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+int launch_fill_keys(uint64_t *keys, size_t n, hipStream_t s) {
+    if (n == 0) return STEREO_OK;
+    hipLaunchKernelGGL(fill_keys_kernel, dim3(ew_grid(n)), dim3(256), 0, s, keys, n);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+int launch_keys_to_i64(const uint64_t *keys, int64_t *out, size_t n, hipStream_t s) {
+    if (n == 0) return STEREO_OK;
+    hipLaunchKernelGGL(keys_flip_kernel, dim3(ew_grid(n)), dim3(256), 0, s, keys, reinterpret_cast<uint64_t *>(out), n);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+int launch_keys_from_i64(const int64_t *in, uint64_t *keys, size_t n, hipStream_t s) {
+    if (n == 0) return STEREO_OK;
+    hipLaunchKernelGGL(keys_flip_kernel, dim3(ew_grid(n)), dim3(256), 0, s, reinterpret_cast<const uint64_t *>(in), keys, n);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+}  // namespace shp

@@ -1,0 +1,369 @@
+"""GPU parity: the drop-in modules (census / guided_filter / filters / stereo, i.e. the C ABI of
+libstereo_hip.so) against the golden vectors captured from the reference and against the CPU
+oracle on seeded inputs.
+
+Bars: the WCT cost volume, disparities of integer-valued filters and every index result are
+bit-exact; float filter outputs agree within 1e-5 relative (BASELINE.json north_star), and a
+disparity may differ from the reference only where the reference's own filtered costs of the two
+candidates are within that tolerance ("gap-aware").
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def assert_wta_matches(disp, cost, disp_ref, cost_ref, layers_ref=None, min_agree=0.999, tol=TOL):
+    """Costs within tol; disparities identical on >= min_agree of the pixels and every mismatch
+    gap-checked against the reference's filtered layers when they are available."""
+    assert disp.dtype == np.int32 and cost.dtype == np.float32
+    assert disp.shape == disp_ref.shape
+    finite = np.isfinite(cost_ref)
+    assert np.array_equal(np.isfinite(cost), finite)
+    assert rel_err(cost[finite], cost_ref[finite]) <= tol
+    bad = np.argwhere(disp != disp_ref)
+    agree = 1.0 - len(bad) / max(disp.size, 1)
+    assert agree >= min_agree, f"only {agree:.5f} of the disparities agree"
+    if layers_ref is not None:
+        for y, x in bad:
+            f_at = float(layers_ref[disp[y, x], y, x])
+            m = float(cost_ref[y, x])
+            assert abs(f_at - m) <= tol * max(1.0, abs(m)), (y, x, f_at, m)
+    return agree
+
+
+# ------------------------------------------------------------------------------- census / DSI
+
+@pytest.mark.parametrize("name", ["guided_48x80x16", "guided_64x96x32", "guided_40x64x12_gr5"])
+def test_dsi_bit_exact_golden(name):
+    import census
+    g = load_golden(name)
+    calls = []
+    dsi = census.compute_wct_cost_volume(g["left"], g["right"], int(g["dmax"]), radius=int(g["wct_radius"]),
+                                         progress_callback=lambda c, t, l: calls.append((c, t, l)))
+    assert dsi.dtype == np.float32 and dsi.flags["C_CONTIGUOUS"]
+    assert np.array_equal(dsi, g["dsi"])
+    dmax = int(g["dmax"])
+    assert calls[-1] == (dmax, dmax, "WCT cost volume") and len(calls) == (dmax + 7) // 8
+
+
+def test_dsi_edge_cases_golden():
+    import census
+    g = load_golden("edge_cases")
+    assert np.array_equal(census.compute_wct_cost_volume(g["wide_left"], g["wide_right"], 28), g["wide_dsi"])
+    assert np.array_equal(census.compute_wct_cost_volume(g["u8_left"], g["u8_right"], 8), g["u8_dsi"])
+    assert np.array_equal(census.compute_wct_cost_volume(g["const_img"], g["const_img"], 4), g["const_dsi"])
+    assert np.array_equal(census.compute_wct_cost_volume(g["nd_left"], g["nd_right"], 8, base_weight=3.3), g["nd_dsi"])
+    assert np.array_equal(census.compute_wct_cost_volume(g["f64_left"], g["f64_right"], 6), g["f64_dsi"])
+    assert np.array_equal(census.compute_wct_cost_volume(g["thin_img"], g["thin_img"], 3), g["thin_dsi"])
+    assert np.array_equal(census.compute_wct_cost_volume(g["small_left"], g["small_right"], 3, radius=1), g["small_dsi"])
+    r8 = load_golden("radius8_40x72x12")
+    assert np.array_equal(census.compute_wct_cost_volume(r8["left"], r8["right"], 12, radius=8), r8["dsi"])
+
+
+@pytest.mark.parametrize("radius,base", [(1, 8.0), (2, 8.0), (3, 4.0), (4, 8.0), (5, 8.0), (6, 2.0), (7, 8.0), (8, 8.0),
+                                         (4, 3.3), (8, 0.7), (4, 1e-3)])
+def test_dsi_bit_exact_oracle(oracle, radius, base):
+    import census
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(70, 150, 40, seed=100 + radius)
+    ref = oracle.wct_cost_volume(left, right, 40, radius=radius, base_weight=base)
+    got = census.compute_wct_cost_volume(left, right, 40, radius=radius, base_weight=base)
+    assert np.array_equal(got, ref)
+
+
+def test_dsi_other_dtypes(oracle):
+    import census
+    rng = np.random.default_rng(3)
+    u16 = rng.integers(0, 65535, size=(40, 60)).astype(np.uint16)
+    r16 = np.roll(u16, -3, axis=1)
+    ref = oracle.wct_cost_volume(u16.astype(np.float64), r16.astype(np.float64), 9)
+    assert np.array_equal(census.compute_wct_cost_volume(u16, r16, 9), ref)
+    i32 = rng.integers(-2**31, 2**31 - 1, size=(40, 60)).astype(np.int32)
+    ref = oracle.wct_cost_volume(i32.astype(np.float64), np.roll(i32, -2, 1).astype(np.float64), 5)
+    assert np.array_equal(census.compute_wct_cost_volume(i32, np.roll(i32, -2, 1), 5), ref)
+
+
+def test_census_validation():
+    import census
+    img = np.zeros((12, 12), dtype=np.float32)
+    with pytest.raises(ValueError):
+        census.compute_wct_cost_volume(np.zeros((3, 4, 5), np.float32), img, 4)
+    with pytest.raises(ValueError):
+        census.compute_wct_cost_volume(img, np.zeros((12, 13), np.float32), 4)
+    with pytest.raises(ValueError):
+        census.compute_wct_cost_volume(img, img, 0)
+    with pytest.raises(ValueError):
+        census.compute_wct_cost_volume(img, img, 4, parallel_chunk=0)
+    with pytest.raises(ValueError):
+        census.compute_wct_cost_volume(img, img, 4, radius=0)
+    with pytest.raises(ValueError):
+        census.generate_offsets(0)
+    g = load_golden("offsets_weights")
+    assert np.array_equal(np.asarray(census.generate_offsets(4), dtype=np.int32), g["off4"])
+    assert np.array_equal(census.compute_weights(census.generate_offsets(8)), g["w8"])
+    assert np.array_equal(census.compute_weights(census.generate_offsets(4), 3.3), g["w_nd"])
+
+
+# ------------------------------------------------------------------------------- guided filter
+
+def test_integral_and_box_golden():
+    import guided_filter as gf
+    g = load_golden("operators_48x80")
+    # integer-valued data sums exactly in float64 whatever the association order
+    assert np.array_equal(gf.integral_image(g["layer"]), g["integral_layer"])
+    assert rel_err(gf.integral_image(g["left"]), g["integral_left"]) <= 1e-12
+    assert rel_err(gf.box_filter_mean(g["left"], 3), g["box3_left"]) <= 1e-12
+    assert rel_err(gf.box_filter_mean(g["left"], 0), g["box0_left"]) <= 1e-12
+    assert np.array_equal(gf.box_filter_mean(g["layer"], 9), g["box9_layer"])
+    out = gf.box_filter_mean(g["left"], 3)
+    assert out.dtype == np.float64 and out.shape == (48, 80)
+    ones = np.ones((37, 29))
+    assert np.array_equal(gf.integral_image(ones), np.outer(np.arange(38.0), np.arange(30.0)))
+    assert np.array_equal(gf.box_filter_mean(ones * 7.0, 5), ones * 7.0)
+    with pytest.raises((ValueError, IndexError)):  # the reference indexes shape[1] first
+        gf.box_filter_mean(np.zeros(5), 1)
+
+
+def test_integral_large_random(oracle):
+    import guided_filter as gf
+    rng = np.random.default_rng(12)
+    img = rng.random((300, 517)) * 100.0
+    assert rel_err(gf.integral_image(img), oracle.integral_image(img)) <= 1e-12
+    assert rel_err(gf.box_filter_mean(img, 7), oracle.box_filter_mean(img, 7)) <= 1e-11
+
+
+def test_guided_filter_golden():
+    import guided_filter as gf
+    g = load_golden("operators_48x80")
+    out = gf.guided_filter(g["left"], g["layer"], 3, 0.0154)
+    assert out.dtype == np.float32
+    assert rel_err(out, g["guided_layer"]) <= 1e-6
+    assert rel_err(gf.guided_filter(g["rnd_guide"], g["rnd_src"], 2, 1e-3), g["guided_rnd_r2"]) <= 1e-6
+    # constant layer maps to itself exactly
+    const = np.full((48, 80), 1200.0, dtype=np.float32)
+    assert np.all(gf.guided_filter(g["left"], const, 3, 0.0154) == 1200.0)
+    pre = gf.prepare_guided_filter(g["left"], 3, 0.0154)
+    gg = load_golden("guided_48x80x16")
+    assert rel_err(pre.mean_guide, gg["mean_guide"]) <= 1e-12 and rel_err(pre.var_g, gg["var_g"]) <= 1e-10
+    assert rel_err(gf.guided_filter_with_precompute(pre, g["layer"]), g["guided_layer"]) <= 1e-6
+    with pytest.raises(ValueError):
+        gf.guided_filter(g["left"], g["layer"][:, :-1], 3, 0.0154)
+    with pytest.raises(ValueError):
+        gf.prepare_guided_filter(g["left"], 0, 0.0154)
+    with pytest.raises(ValueError):
+        gf.prepare_guided_filter(g["left"], 3, 0.0)
+
+
+@pytest.mark.parametrize("radius", [1, 2, 3, 4, 6, 9])
+def test_guided_filter_radii_oracle(oracle, radius):
+    import guided_filter as gf
+    rng = np.random.default_rng(radius)
+    guide = rng.random((75, 131)).astype(np.float32)
+    src = (rng.random((75, 131)) * 1200.0).astype(np.float32)
+    ref = oracle.guided_filter(guide, src, radius, 0.0154)
+    assert rel_err(gf.guided_filter(guide, src, radius, 0.0154), ref) <= 1e-6
+
+
+# ------------------------------------------------------------------------------- fused pipeline
+
+@pytest.mark.parametrize("name", ["guided_48x80x16", "guided_64x96x32"])
+def test_compute_disparity_golden(name, oracle):
+    import stereo
+    g = load_golden(name)
+    dmax = int(g["dmax"])
+    calls = []
+    disp, cost = stereo.compute_disparity(g["left"], g["right"], dmax, guided_eps=float(g["guided_eps"]),
+                                          progress_callback=lambda c, t, l: calls.append((c, t, l)))
+    layers = g["guided_layers"] if "guided_layers" in g.files else oracle.aggregate_and_wta(
+        g["dsi"], g["left"], oracle.FILTER_GUIDED, 3, float(g["guided_eps"]), want_layers=True)[2]
+    assert_wta_matches(disp, cost, g["disparity"], g["min_cost"], layers)
+    assert calls[-1] == (dmax, dmax, "Guided Filter")
+    assert sum(1 for c in calls if c[2] == "Guided Filter") == dmax
+    # the two-call path (materialised volume) gives the same answer
+    d2, c2 = stereo.aggregate_and_wta(g["dsi"], g["left"], 3, float(g["guided_eps"]))
+    assert_wta_matches(d2, c2, g["disparity"], g["min_cost"], layers)
+
+
+def test_compute_disparity_edge_cases_golden(oracle):
+    import stereo
+    g = load_golden("edge_cases")
+
+    def layers_of(dsi, guide, r=3):
+        return oracle.aggregate_and_wta(dsi, guide, oracle.FILTER_GUIDED, r, 0.0154, want_layers=True)[2]
+
+    d, c = stereo.compute_disparity(g["wide_left"], g["wide_right"], 28, guided_eps=0.0154, show_progress=False)
+    assert_wta_matches(d, c, g["wide_disp"], g["wide_cost"], layers_of(g["wide_dsi"], g["wide_left"]))
+    d, c = stereo.compute_disparity(g["u8_left"], g["u8_right"], 8, guided_eps=0.0154, show_progress=False)
+    assert_wta_matches(d, c, g["u8_disp"], g["u8_cost"], layers_of(g["u8_dsi"], g["u8_left"]))
+    d, c = stereo.compute_disparity(g["const_img"], g["const_img"], 4, guided_eps=0.0154, show_progress=False)
+    assert_wta_matches(d, c, g["const_disp"], g["const_cost"], layers_of(g["const_dsi"], g["const_img"]))
+    d, c = stereo.compute_disparity(g["nd_left"], g["nd_right"], 8, base_weight=3.3, guided_eps=0.0154,
+                                    show_progress=False)
+    assert_wta_matches(d, c, g["nd_disp"], g["nd_cost"], layers_of(g["nd_dsi"], g["nd_left"]))
+    d, c = stereo.compute_disparity(g["small_left"], g["small_right"], 3, wct_radius=1, guided_eps=0.0154,
+                                    show_progress=False)
+    assert_wta_matches(d, c, g["small_disp"], g["small_cost"], layers_of(g["small_dsi"], g["small_left"]))
+    g5 = load_golden("guided_40x64x12_gr5")  # guided radius 5: layer-at-a-time general path
+    d, c = stereo.compute_disparity(g5["left"], g5["right"], 12, guided_radius=5, guided_eps=0.01, show_progress=False)
+    lay5 = oracle.aggregate_and_wta(g5["dsi"], g5["left"], oracle.FILTER_GUIDED, 5, 0.01, want_layers=True)[2]
+    assert_wta_matches(d, c, g5["disparity"], g5["min_cost"], lay5)
+    r8 = load_golden("radius8_40x72x12")
+    d, c = stereo.compute_disparity(r8["left"], r8["right"], 12, wct_radius=8, guided_eps=0.0154, show_progress=False)
+    assert_wta_matches(d, c, r8["disp_guided"], r8["cost_guided"], layers_of(r8["dsi"], r8["left"]))
+
+
+@pytest.mark.parametrize("h,w,dmax,rg,seed", [(97, 211, 40, 3, 1), (33, 52, 17, 3, 2), (130, 300, 64, 2, 3),
+                                               (64, 53, 9, 4, 4), (31, 105, 30, 1, 5)])
+def test_compute_disparity_oracle_shapes(oracle, h, w, dmax, rg, seed):
+    """Tile-boundary shapes (tiles are 32 rows x (64 - 4r) columns) against the oracle."""
+    import stereo
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(h, w, dmax, seed)
+    dsi = oracle.wct_cost_volume(left, right, dmax)
+    dref, cref, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, rg, 0.0154, want_layers=True)
+    d, c = stereo.compute_disparity(left, right, dmax, guided_radius=rg, guided_eps=0.0154, show_progress=False)
+    assert_wta_matches(d, c, dref, cref, layers)
+
+
+def test_filtered_layers_match_oracle(oracle):
+    """Every filtered cost of every layer within 1e-5 relative (not only the winning one)."""
+    import guided_filter as gf
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(80, 140, 24, seed=9)
+    dsi = oracle.wct_cost_volume(left, right, 24)
+    _, _, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, 3, 0.0154, want_layers=True)
+    worst = 0.0
+    for d in range(24):
+        worst = max(worst, rel_err(gf.guided_filter(left, dsi[:, :, d], 3, 0.0154), layers[d]))
+    assert worst <= 1e-6, worst
+
+
+def test_disparity_shards_merge_bit_exact():
+    """Any partition of [0, D) merged with the lexicographic (cost, d) min equals the unsharded run."""
+    import stereo
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(90, 160, 48, seed=21)
+    d_all, c_all = stereo.compute_disparity(left, right, 48, guided_eps=0.0154, show_progress=False)
+    for cuts in ([0, 24, 48], [0, 5, 6, 30, 48], [0, 48, 48]):
+        best_c = np.full(c_all.shape, np.inf, dtype=np.float32)
+        best_d = np.zeros(d_all.shape, dtype=np.int32)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            d, c = stereo.compute_disparity(left, right, 48, guided_eps=0.0154, show_progress=False, d_begin=a, d_end=b)
+            better = (c < best_c) | ((c == best_c) & (d < best_d) & np.isfinite(c))
+            best_c = np.where(better, c, best_c)
+            best_d = np.where(better, d, best_d)
+        assert np.array_equal(best_d, d_all) and np.array_equal(best_c, c_all)
+
+
+def test_wta_semantics_golden():
+    import stereo
+    g = load_golden("wta_semantics")
+    d, c = stereo.aggregate_and_wta(g["layers"], g["guide"], 3, 0.0154, filter_type="median", median_radius=1,
+                                    median_method="scipy")
+    assert d.dtype == np.int32 and c.dtype == np.float32
+    # layers are constant planes (except two pixels), so a 3x3 median leaves the interior unchanged
+    assert d[3, 3] == 1 and c[3, 3] == 1.0
+
+
+def test_stereo_validation():
+    import stereo
+    img = np.zeros((16, 16), dtype=np.float32)
+    dsi = np.zeros((16, 16, 4), dtype=np.float32)
+    with pytest.raises(ValueError):
+        stereo.compute_disparity(img, np.zeros((16, 17), np.float32), 4, show_progress=False)
+    with pytest.raises(ValueError):
+        stereo.compute_disparity(np.zeros((2, 3, 4), np.float32), np.zeros((2, 3, 4), np.float32), 4, show_progress=False)
+    with pytest.raises(ValueError):
+        stereo.compute_disparity(img, img, 0, show_progress=False)
+    with pytest.raises(ValueError):
+        stereo.compute_disparity(img, img, 4, filter_type="boxcar", show_progress=False)
+    with pytest.raises(ValueError):
+        stereo.compute_disparity(img, img, 4, guided_eps=0.0, show_progress=False)
+    with pytest.raises(ValueError):
+        stereo.aggregate_and_wta(img, img, 3, 0.01)
+    with pytest.raises(ValueError):
+        stereo.aggregate_and_wta(dsi, dsi, 3, 0.01)
+    with pytest.raises(ValueError):
+        stereo.aggregate_and_wta(dsi, np.zeros((16, 15), np.float32), 3, 0.01)
+    with pytest.raises(ValueError):
+        stereo.aggregate_and_wta(dsi, img, 3, 0.01, filter_type=" nope ")
+    with pytest.raises(ValueError):
+        stereo.aggregate_and_wta(dsi, img, 0, 0.01)
+    d, c = stereo.aggregate_and_wta(dsi, img, 3, 0.01, filter_type=" Guided ")
+    assert d.shape == (16, 16)
+
+
+# ------------------------------------------------------------------------------- other filters
+
+def test_filters_single_layer_golden():
+    import filters
+    g = load_golden("filters_48x80")
+    for method in ("scipy", "vectorized", "naive"):
+        out = filters.median_filter(g["layer"], 3, method=method)
+        assert out.dtype == np.float32 and np.array_equal(out, g["median_r3"])
+    assert np.array_equal(filters.median_filter(g["rnd_src"], 1, method="scipy"), g["median_rnd_r1"])
+    assert np.array_equal(filters.median_filter(g["layer"], 3), g["median_opencv_pin_r3"])
+    assert np.array_equal(filters.median_filter(g["u8_quantised"], 3),
+                          filters.median_filter(g["u8_quantised"].astype(np.float32), 3, method="naive"))
+    assert rel_err(filters.gaussian_filter(g["layer"], 1.0), g["gaussian_s1"]) <= 2e-6
+    assert rel_err(filters.gaussian_filter(g["rnd_src"], 0.7, method="naive"), g["gaussian_rnd_s07"]) <= 2e-6
+    assert rel_err(filters.bilateral_filter(g["layer"], 1.0), g["bilateral_s1"]) <= TOL
+    assert rel_err(filters.bilateral_filter(g["rnd_src"], 1.5), g["bilateral_rnd_s15"]) <= TOL
+    with pytest.raises(ValueError):
+        filters.median_filter(g["layer"], 0)
+    with pytest.raises(ValueError):
+        filters.median_filter(g["layer"], 3, method="fast")
+    with pytest.raises(ValueError):
+        filters.median_filter(np.full((8, 8), np.nan, dtype=np.float32), 1)
+    with pytest.raises(ValueError):
+        filters.gaussian_filter(g["layer"], 0.0)
+    with pytest.raises(ValueError):
+        filters.gaussian_filter(g["layer"], 1.0, method="fft")
+    with pytest.raises(ValueError):
+        filters.bilateral_filter(g["layer"], -1.0)
+    const = np.full((20, 30), 7.5, dtype=np.float32)
+    assert np.all(filters.median_filter(const, 2) == 7.5)
+
+
+def test_filters_through_wta_golden(oracle):
+    import stereo
+    g = load_golden("wta_filters_48x80x16")
+    dsi, left = g["dsi"], g["left"]
+    d, c = stereo.aggregate_and_wta(dsi, left, 3, 0.0154, filter_type="median", median_method="scipy")
+    assert np.array_equal(d, g["disp_median"]) and np.array_equal(c, g["cost_median"])
+    d, c = stereo.aggregate_and_wta(dsi, left, 3, 0.0154, filter_type="median")
+    assert np.array_equal(d, g["disp_median_opencv_pin"]) and np.array_equal(c, g["cost_median_opencv_pin"])
+    lay = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GAUSSIAN, 0, 1.0, want_layers=True)[2]
+    d, c = stereo.aggregate_and_wta(dsi, left, 3, 0.0154, filter_type="gaussian")
+    assert_wta_matches(d, c, g["disp_gaussian_pin"], g["cost_gaussian_pin"], lay)
+    lay = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_BILATERAL, 0, 1.0, want_layers=True)[2]
+    d, c = stereo.aggregate_and_wta(dsi, left, 3, 0.0154, filter_type="bilateral")
+    assert_wta_matches(d, c, g["disp_bilateral"], g["cost_bilateral"], lay, min_agree=0.95)
+
+
+def test_radius8_filters_fused_golden(oracle):
+    """BASELINE config 5 in miniature: census radius 8 with median / gaussian / bilateral."""
+    import stereo
+    g = load_golden("radius8_40x72x12")
+    left, right, dsi = g["left"], g["right"], g["dsi"]
+    d, c = stereo.compute_disparity(left, right, 12, wct_radius=8, filter_type="median", show_progress=False)
+    assert np.array_equal(d, g["disp_median_opencv_pin"]) and np.array_equal(c, g["cost_median_opencv_pin"])
+    lay = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GAUSSIAN, 0, 1.0, want_layers=True)[2]
+    d, c = stereo.compute_disparity(left, right, 12, wct_radius=8, filter_type="gaussian", show_progress=False)
+    assert_wta_matches(d, c, g["disp_gaussian_pin"], g["cost_gaussian_pin"], lay)
+    lay = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_BILATERAL, 0, 1.0, want_layers=True)[2]
+    d, c = stereo.compute_disparity(left, right, 12, wct_radius=8, filter_type="bilateral", show_progress=False)
+    assert_wta_matches(d, c, g["disp_bilateral"], g["cost_bilateral"], lay, min_agree=0.95)
