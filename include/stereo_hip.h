@@ -131,6 +131,11 @@ int stereo_keys_from_i64_dev(const int64_t *d_in, uint64_t *d_keys, size_t n, vo
 int stereo_unpack_keys_dev(const uint64_t *d_keys, size_t n, int32_t *d_disparity, float *d_min_cost,
                            void *stream);
 
+/* Test hook, no counterpart in the reference: when on, compute_disparity uses the general fused
+ * kernel (float64 sums exchanged through LDS) even where the fast one applies, so the two can
+ * be compared on the same input. */
+int stereo_debug_force_general_kernel(int on);
+
 /* Timing of the dominant (fused) kernel with HIP events recorded on the launch stream, for
  * bench.py's roofline figure; no counterpart in the reference.  stereo_profile_begin creates up
  * to max_launches event pairs and arms recording; stereo_profile_end synchronises, returns the

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "stereo_keys_to_i64_dev": [_VP, _VP, _SZ, _VP],
     "stereo_keys_from_i64_dev": [_VP, _VP, _SZ, _VP],
     "stereo_unpack_keys_dev": [_VP, _SZ, _VP, _VP, _VP],
+    "stereo_debug_force_general_kernel": [_I],
     "stereo_profile_begin": [_I],
     "stereo_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
 }

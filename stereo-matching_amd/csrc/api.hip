@@ -30,6 +30,7 @@ struct ProfileState {
     bool enabled = false;
 };
 static ProfileState g_prof;
+static bool g_force_general = false;  // debugging/testing: route around the fast fused kernel
 
 static int check_params(const StereoParams *p) {
     if (!p) { set_error("params is NULL"); return STEREO_EINVAL; }
@@ -64,7 +65,7 @@ static size_t dtype_size(int dt) { return dt == STEREO_DT_F64 ? 8 : (dt == STERE
 // layout of the fused workspace
 struct FusedWs {
     size_t words_bytes, plane_f64;
-    size_t off_lw, off_rw, off_mean, off_invden, total;
+    size_t off_lw, off_rw, off_mean, off_invden, off_gmax, total;
 };
 static FusedWs fused_ws_layout(int H, int W, int wct_radius) {
     FusedWs w;
@@ -75,7 +76,8 @@ static FusedWs fused_ws_layout(int H, int W, int wct_radius) {
     w.off_rw = w.off_lw + w.words_bytes;
     w.off_mean = w.off_rw + w.words_bytes;
     w.off_invden = w.off_mean + w.plane_f64;
-    w.total = w.off_invden + w.plane_f64;
+    w.off_gmax = w.off_invden + w.plane_f64;
+    w.total = w.off_gmax + 256;
     return w;
 }
 
@@ -105,13 +107,19 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
             set_error("fused guided path supports radius 1..4, got %d", p->guided_radius);
             return STEREO_EUNSUPPORTED;
         }
+        float *gmax = reinterpret_cast<float *>(base + L.off_gmax);
         SHP_TRY(launch_guide_stats(d_left, STEREO_DT_F32, H, W, p->guided_radius, p->guided_eps, mean, invden,
-                                   nullptr, s));
+                                   gmax, s));
         if (d_begin == d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
+        const bool fast = fused_fast_supported(cfg, p->guided_radius) && !g_force_general;
+        const int slices = fast ? fused_fast_slices(H, W, p->guided_radius, d_end - d_begin) : 1;
+        if (fast && slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
         const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();
         if (prof) SHP_HIP(hipEventRecord(g_prof.start[g_prof.used], s));
-        int rc = launch_fused_guided(lw, rw, &cfg, nullptr, d_left, STEREO_DT_F32, mean, invden, H, W, dmax,
-                                     p->guided_radius, d_begin, d_end, d_keys, d_q_out, 0, s);
+        int rc = fast ? launch_fused_guided_fast(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius,
+                                                 d_begin, d_end, slices, d_keys, d_q_out, s)
+                      : launch_fused_guided(lw, rw, &cfg, nullptr, d_left, STEREO_DT_F32, mean, invden, H, W, dmax,
+                                            p->guided_radius, d_begin, d_end, d_keys, d_q_out, 0, s);
         if (prof) {
             SHP_HIP(hipEventRecord(g_prof.stop[g_prof.used], s));
             ++g_prof.used;
@@ -283,6 +291,11 @@ int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int 
                                  uint64_t *d_keys, void *stream) {
     return fused_disparity_dev(d_left, d_right, H, W, dmax, p, d_begin, d_end, ws, ws_bytes, d_keys, nullptr,
                                static_cast<hipStream_t>(stream));
+}
+
+int stereo_debug_force_general_kernel(int on) {
+    g_force_general = on != 0;
+    return STEREO_OK;
 }
 
 int stereo_profile_begin(int max_launches) {

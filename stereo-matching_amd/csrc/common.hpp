@@ -114,8 +114,9 @@ int launch_keys_to_i64(const uint64_t *keys, int64_t *out, size_t n, hipStream_t
 int launch_keys_from_i64(const int64_t *in, uint64_t *keys, size_t n, hipStream_t s);
 
 // guided filter
+// d_gmax (optional, 4 bytes): receives max |guide| as a float32
 int launch_guide_stats(const void *d_guide, int guide_dtype, int H, int W, int radius, double eps,
-                       double *d_mean, double *d_invden, void *d_scratch, hipStream_t s);
+                       double *d_mean, double *d_invden, void *d_gmax, hipStream_t s);
 size_t guide_stats_scratch_bytes(int H, int W, int radius);
 bool fused_guided_supported(int guided_radius);
 // cost source: census words (d_lw/d_rw, cfg) when d_dsi == nullptr, else the materialised volume.
@@ -124,6 +125,14 @@ int launch_fused_guided(const void *d_lw, const void *d_rw, const CensusCfg *cfg
                         int H, int W, int dmax, int guided_radius, int d_begin, int d_end, uint64_t *d_keys,
                         float *d_q_out, int atomic_out, hipStream_t s);
 
+
+// fast fused kernel (guided_fast.hip): exact census weights, float32 guide, guided radius <= 4
+bool fused_fast_supported(const CensusCfg &cfg, int guided_radius);
+int fused_fast_slices(int H, int W, int guided_radius, int n_disp);
+int launch_fused_guided_fast(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
+                             const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
+                             int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
+                             float *d_q_out, hipStream_t s);
 
 int launch_dsi_layers(const void *d_lw, const void *d_rw, int H, int W, int d_begin, int d_end, const CensusCfg &cfg,
                       float *d_layers, hipStream_t s);

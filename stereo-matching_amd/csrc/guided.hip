@@ -32,7 +32,7 @@ constexpr int GS_TW = 64, GS_TH = 16;
 template <typename GT>
 __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__ guide, int H, int W, int R,
                                                           double eps32, double *__restrict__ mean,
-                                                          double *__restrict__ invden) {
+                                                          double *__restrict__ invden, unsigned int *gmax_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *tile = reinterpret_cast<double *>(smem_raw);  // [LH][LW] guide, 0 outside the image
     const int LW = GS_TW + 2 * R, LH = GS_TH + 2 * R;
@@ -59,10 +59,13 @@ __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__
         hs2[i] = s2;
     }
     __syncthreads();
+    float amax = 0.f;  // max |guide| over the tile, as float32 (NaN sticks through the bit compare)
     for (int i = threadIdx.x; i < GS_TH * GS_TW; i += blockDim.x) {
         int ly = i >> 6, lx = i & 63;
         int gy = y0 + ly, gx = x0 + lx;
         if (gy >= H || gx >= W) continue;
+        float ag = fabsf((float)tile[(ly + R) * LW + lx + R]);
+        amax = (__float_as_uint(ag) > __float_as_uint(amax)) ? ag : amax;
         double s1 = 0.0, s2 = 0.0;
         for (int k = 0; k <= 2 * R; ++k) {
             s1 += hs1[(ly + k) * GS_TW + lx];
@@ -80,13 +83,23 @@ __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__
         mean[(size_t)gy * W + gx] = m;
         invden[(size_t)gy * W + gx] = 1.0 / den;
     }
+    if (gmax_bits) {
+        unsigned int b = __float_as_uint(amax);
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned int o = __shfl_down(b, off, 64);
+            b = o > b ? o : b;
+        }
+        if ((threadIdx.x & 63) == 0 && b) atomicMax(gmax_bits, b);
+    }
 }
 
 size_t guide_stats_scratch_bytes(int, int, int) { return 0; }
 
 int launch_guide_stats(const void *d_guide, int guide_dtype, int H, int W, int radius, double eps,
-                       double *d_mean, double *d_invden, void *, hipStream_t s) {
+                       double *d_mean, double *d_invden, void *d_gmax, hipStream_t s) {
     if (H <= 0 || W <= 0) return STEREO_OK;
+    unsigned int *gmax_bits = static_cast<unsigned int *>(d_gmax);
+    if (gmax_bits) SHP_HIP(hipMemsetAsync(gmax_bits, 0, 4, s));
     if (radius < 1 || radius > 16) {
         set_error("guide statistics kernel supports radius 1..16, got %d", radius);
         return STEREO_EUNSUPPORTED;
@@ -97,10 +110,10 @@ int launch_guide_stats(const void *d_guide, int guide_dtype, int H, int W, int r
     size_t smem = sizeof(double) * ((size_t)LW * LH + 2 * (size_t)LH * GS_TW);
     if (guide_dtype == STEREO_DT_F32)
         hipLaunchKernelGGL(guide_stats_kernel<float>, grid, dim3(256), smem, s,
-                           static_cast<const float *>(d_guide), H, W, radius, eps32, d_mean, d_invden);
+                           static_cast<const float *>(d_guide), H, W, radius, eps32, d_mean, d_invden, gmax_bits);
     else if (guide_dtype == STEREO_DT_F64)
         hipLaunchKernelGGL(guide_stats_kernel<double>, grid, dim3(256), smem, s,
-                           static_cast<const double *>(d_guide), H, W, radius, eps32, d_mean, d_invden);
+                           static_cast<const double *>(d_guide), H, W, radius, eps32, d_mean, d_invden, gmax_bits);
     else {
         set_error("guide dtype must be float32 or float64");
         return STEREO_EINVAL;

@@ -1,0 +1,305 @@
+// Fast path of the fused census-cost + guided-filter + WTA kernel (float32 guide, exactly
+// summable census weights, guided radius <= 4).  Same decomposition as guided.hip -- a
+// workgroup owns a TH x (64 - 4r) tile, each wavefront marches down the tile rows for one
+// disparity at a time with one lane per column -- but the horizontal box sums never touch LDS:
+//
+//  * Stage 1 (box sums of p and G*p) is exact 32-bit arithmetic.  p is an integer number of
+//    cost units; G is split as k * 2^-s + g_lo with k a 16-bit integer chosen so that the
+//    window sum of k*p fits an int32, and g_lo = G - k*2^-s (exact in float32, |g_lo| <= 2^-s-1).
+//    sum(G*p) = 2^-s * sum(k*p) [exact integers] + sum(g_lo*p) [tiny float32 terms].
+//    The three 32-bit running sums are summed across 2r+1 neighbouring lanes with a chain of
+//    v_add_*_dpp wave_shr:1 instructions (s_t = v + shift(s_{t-1})).
+//  * a, b and their vertical running sums stay float64 as in the reference.
+//  * Stage 2 (box sums of a and b) is reduced to two float32 chains: with c0 the guide value
+//    of the wavefront's centre lane, box(a)*G + box(b) = sum(E) + (G - c0) * sum(A) where
+//    E = A*c0 + B carries no cancellation (it is the filter output for a guide equal to c0),
+//    so float32 is enough for E and for A (which is multiplied by the small G - c0).
+//    The chain runs the other way (wave_shl:1) so outputs land back on their own lane.
+//  * The final scaling by 1/area is done in float64 so that a constant window returns the
+//    constant exactly (ties between all-`large` layers must stay ties).
+#include <type_traits>
+
+#include "census_dev.hpp"
+
+namespace shp {
+
+struct FastArgs {
+    const void *lw;         // left census words
+    const void *rw;         // right census words
+    const float *guide;     // [H][W]
+    const double *mean;     // [H][W] box mean of the guide
+    const double *invden;   // [H][W] 1 / (var + eps32)
+    const float *gmax;      // max |guide| (device scalar)
+    uint64_t *keys;         // [H][W] packed (cost, d)
+    float *q_out;           // optional [D][H][W]
+    int H, W, D;
+    int d_begin, d_end;     // disparity range of the launch
+    int n_slices;           // gridDim.z; slice z handles every n_slices-th chunk of the range
+    int radius;             // census radius
+    float unit;             // value of one cost unit
+    uint32_t large_units;   // `large` in cost units
+    int atomic_out;
+};
+
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+template <int RG, bool WORD64, int TH, int NW>
+__global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) {
+    constexpr int WIN = 2 * RG + 1;
+    constexpr int HALO = 2 * RG;
+    constexpr int NI = TH + 4 * RG;
+    constexpr int NJ = TH + 2 * RG;
+    constexpr int TWV = 64 - 4 * RG;
+    using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char *sp = smem_raw;
+    double *mG_s = reinterpret_cast<double *>(sp); sp += sizeof(double) * NJ * 64;
+    uint64_t *key_s = reinterpret_cast<uint64_t *>(sp); sp += sizeof(uint64_t) * TH * 64;
+    double *invtab = reinterpret_cast<double *>(sp); sp += sizeof(double) * 16;
+    WordT *L_s = reinterpret_cast<WordT *>(sp); sp += sizeof(WordT) * NI * 64;
+    float *inv_s = reinterpret_cast<float *>(sp); sp += sizeof(float) * NJ * 64;
+    float *G_s = reinterpret_cast<float *>(sp); sp += sizeof(float) * NI * 64;
+    short *k_s = reinterpret_cast<short *>(sp);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H = a.H, W = a.W;
+    const int tx0 = blockIdx.x * TWV, ty0 = blockIdx.y * TH;
+    const WordT *lw = static_cast<const WordT *>(a.lw);
+    const WordT *rw = static_cast<const WordT *>(a.rw);
+
+    // guide quantisation: |k| <= kmax keeps the (2r+1)^2-window sum of k*p inside int32
+    const float gmax = *a.gmax;
+    int kmax = (int)(2147483647u / ((uint32_t)(WIN * WIN) * max(a.large_units, 1u)));
+    kmax = min(kmax, 32767);
+    int sh = 0;
+    if (gmax > 0.f && gmax < 3.0e38f) sh = min(max(ilogbf((float)kmax / gmax), -120), 120);
+    const float scale_f = ldexpf(1.f, sh);
+    const float inv_scale_f = ldexpf(1.f, -sh);
+    const double inv_scale_d = (double)inv_scale_f;
+
+    for (int idx = threadIdx.x; idx < NI * 64; idx += NW * 64) {
+        int i = idx >> 6, l = idx & 63;
+        int gy = ty0 - HALO + i, gx = tx0 - HALO + l;
+        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        float g = in ? a.guide[(size_t)gy * W + gx] : 0.f;
+        G_s[idx] = g;
+        k_s[idx] = (short)__float2int_rn(g * scale_f);
+        L_s[idx] = in ? lw[(size_t)gy * W + gx] : WordT(0);
+    }
+    for (int idx = threadIdx.x; idx < NJ * 64; idx += NW * 64) {
+        int j = idx >> 6, l = idx & 63;
+        int gy = ty0 - RG + j, gx = tx0 - HALO + l;
+        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        mG_s[idx] = in ? a.mean[(size_t)gy * W + gx] : 0.0;
+        inv_s[idx] = in ? (float)a.invden[(size_t)gy * W + gx] : 0.f;
+    }
+    for (int idx = threadIdx.x; idx < TH * 64; idx += NW * 64) key_s[idx] = SHP_KEY_INIT;
+    if (threadIdx.x <= WIN) invtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
+    __syncthreads();
+
+    const int x = tx0 - HALO + lane;   // column of this lane's cost and of its final output
+    const int x1 = x - RG;             // column of this lane's stage-1 result (a, b)
+    const bool x_in = x >= 0 && x < W;
+    const bool x1_in = x1 >= 0 && x1 < W && lane >= RG;
+    const int cx = x_in ? (min(x + RG, W - 1) - max(x - RG, 0) + 1) : 0;
+    const int cx1 = x1_in ? (min(x1 + RG, W - 1) - max(x1 - RG, 0) + 1) : 0;
+    const double invAX1 = invtab[cx1];
+    const double invAX2 = invtab[cx] * (double)a.unit;
+    const int R = a.radius;
+    const bool x_valid = x_in && x >= R && x < W - R;
+    const bool out_lane = lane >= HALO && lane < 64 - HALO && x < W;
+    const uint32_t large_u = a.large_units;
+
+    // disparities of this slice, dealt to the wavefronts round-robin
+    const int slice = blockIdx.z;
+    for (int d = a.d_begin + slice * NW + wave; d < a.d_end; d += NW * a.n_slices) {
+        uint32_t C1 = 0u;
+        int I2 = 0;
+        float F2 = 0.f;
+        double A = 0.0, B = 0.0;
+        uint32_t pr[WIN];
+        int kr[WIN];
+        float gr[WIN];
+        double ar[WIN], br[WIN];
+        WordT rcur[WIN], rnext[WIN];
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) { pr[k] = 0u; kr[k] = 0; gr[k] = 0.f; ar[k] = 0.0; br[k] = 0.0; }
+        const bool xd_valid = x_valid && (x - d >= R);
+        const size_t xr = (size_t)(x - d);
+        // right census words of the first row group
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const int yi = ty0 - HALO + k;
+            rnext[k] = (xd_valid && yi >= R && yi < H - R) ? rw[(size_t)yi * W + xr] : WordT(0);
+        }
+
+        for (int base = 0; base < NI; base += WIN) {
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) rcur[k] = rnext[k];
+            if (base + WIN < NI) {
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) {
+                    const int yi = ty0 - HALO + base + WIN + k;
+                    rnext[k] = (xd_valid && yi >= R && yi < H - R && base + WIN + k < NI) ? rw[(size_t)yi * W + xr]
+                                                                                         : WordT(0);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) {
+                const int i = base + k;
+                if (i < NI) {
+                    const int yi = ty0 - HALO + i;
+                    const bool row_in = yi >= 0 && yi < H;
+                    // 1. cost in units; k*p and g_lo*p
+                    const bool valid = xd_valid && yi >= R && yi < H - R;
+                    uint32_t p = valid ? field_sum((WordT)(L_s[i * 64 + lane] ^ rcur[k])) : large_u;
+                    p = (row_in && x_in) ? p : 0u;
+                    const int kk = (int)k_s[i * 64 + lane];
+                    const float g = G_s[i * 64 + lane];
+                    const float glo = fmaf(-(float)kk, inv_scale_f, g);
+                    const int kp = __mul24(kk, (int)p);
+                    const float gl = glo * (float)p;
+                    // 2. vertical running sums over rows [i - 2r, i]
+                    C1 += p - pr[k];
+                    I2 += kp - kr[k];
+                    F2 += gl - gr[k];
+                    pr[k] = p; kr[k] = kp; gr[k] = gl;
+                    if (i >= HALO) {
+                        // 3. sums over lanes [l - 2r, l]: the box sums of column x1 = x - r
+                        uint32_t s1 = C1;
+                        int si = I2;
+                        float sf = F2;
+#pragma unroll
+                        for (int t = 0; t < 2 * RG; ++t) {
+                            s1 = C1 + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)s1);
+                            si = I2 + dpp_i<DPP_WAVE_SHR1>(si);
+                            sf = F2 + dpp_f<DPP_WAVE_SHR1>(sf);
+                        }
+                        // 4. a, b at (row ty0 - r + j, column x1)
+                        const int j = i - HALO;
+                        const int ym = ty0 - RG + j;
+                        double av = 0.0, bv = 0.0;
+                        if (ym >= 0 && ym < H && x1_in) {
+                            const int cy = min(ym + RG, H - 1) - max(ym - RG, 0) + 1;
+                            const double ia = invtab[cy] * invAX1;
+                            const double mP = (double)s1 * ia;
+                            const double mGP = fma((double)si, inv_scale_d, (double)sf) * ia;
+                            const double mG = mG_s[j * 64 + lane - RG];
+                            const double cov = mGP - mG * mP;
+                            av = cov * (double)inv_s[j * 64 + lane - RG];
+                            bv = mP - av * mG;
+                        }
+                        // 5. vertical running sums over stage-1 rows [j - 2r, j]
+                        const int k2 = (k + 1) % WIN;
+                        A += av - ar[k2];
+                        B += bv - br[k2];
+                        ar[k2] = av;
+                        br[k2] = bv;
+                        if (i >= 2 * HALO) {
+                            // 6. sums over lanes [l, l + 2r] (stage-1 columns x - r .. x + r)
+                            const int o = i - 2 * HALO;
+                            const int yo = ty0 + o;
+                            const float gout = G_s[(o + HALO) * 64 + lane];
+                            const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gout), 32));
+                            const float ef = (float)fma(A, (double)c0, B);
+                            const float af = (float)A;
+                            float se = ef, sa = af;
+#pragma unroll
+                            for (int t = 0; t < 2 * RG; ++t) {
+                                se = ef + dpp_f<DPP_WAVE_SHL1>(se);
+                                sa = af + dpp_f<DPP_WAVE_SHL1>(sa);
+                            }
+                            // 7. q and the running WTA
+                            if (out_lane && yo < H) {
+                                const int cy = min(yo + RG, H - 1) - max(yo - RG, 0) + 1;
+                                const float t32 = fmaf(gout - c0, sa, se);
+                                const float qf = (float)((double)t32 * (invtab[cy] * invAX2));
+                                if (a.q_out) a.q_out[((size_t)d * H + yo) * W + x] = qf;
+                                if (qf == qf) atomicMin(reinterpret_cast<unsigned long long *>(&key_s[o * 64 + lane]),
+                                                        (unsigned long long)make_key(qf, (uint32_t)d));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TH * 64; idx += NW * 64) {
+        int o = idx >> 6, l = idx & 63;
+        int gy = ty0 + o, gx = tx0 - HALO + l;
+        if (l >= HALO && l < 64 - HALO && gy < H && gx < W) {
+            uint64_t key = key_s[idx];
+            if (a.atomic_out) atomicMin(reinterpret_cast<unsigned long long *>(&a.keys[(size_t)gy * W + gx]),
+                                        (unsigned long long)key);
+            else a.keys[(size_t)gy * W + gx] = key;
+        }
+    }
+}
+
+constexpr int FF_TH = 64;
+constexpr int FF_NW = 16;
+
+template <int RG, bool WORD64>
+static int launch_fast_t(const FastArgs &a, hipStream_t s) {
+    constexpr int NI = FF_TH + 4 * RG, NJ = FF_TH + 2 * RG, TWV = 64 - 4 * RG;
+    using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
+    size_t smem = sizeof(double) * NJ * 64 + sizeof(uint64_t) * FF_TH * 64 + sizeof(double) * 16 +
+                  sizeof(WordT) * NI * 64 + sizeof(float) * NJ * 64 + sizeof(float) * NI * 64 + sizeof(short) * NI * 64;
+    auto kern = fused_guided_fast_kernel<RG, WORD64, FF_TH, FF_NW>;
+    SHP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem));
+    dim3 grid(ceil_div(a.W, TWV), ceil_div(a.H, FF_TH), a.n_slices);
+    hipLaunchKernelGGL(kern, grid, dim3(FF_NW * 64), smem, s, a);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+bool fused_fast_supported(const CensusCfg &cfg, int guided_radius) {
+    return cfg.exact && guided_radius >= 1 && guided_radius <= 4 && cfg.unit > 0.f;
+}
+
+// Number of disparity slices (gridDim.z) that gives the chip enough workgroups.
+int fused_fast_slices(int H, int W, int guided_radius, int n_disp) {
+    int tiles = ceil_div(W, 64 - 4 * guided_radius) * ceil_div(H, FF_TH);
+    int s = 1;
+    while (tiles * s < 2048 && s * FF_NW * 2 <= n_disp) s *= 2;
+    return s;
+}
+
+int launch_fused_guided_fast(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
+                             const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
+                             int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
+                             float *d_q_out, hipStream_t s) {
+    if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
+    FastArgs a;
+    memset(&a, 0, sizeof(a));
+    a.lw = d_lw; a.rw = d_rw; a.guide = d_guide; a.mean = d_mean; a.invden = d_invden; a.gmax = d_gmax;
+    a.keys = d_keys; a.q_out = d_q_out;
+    a.H = H; a.W = W; a.D = dmax; a.d_begin = d_begin; a.d_end = d_end;
+    a.n_slices = n_slices < 1 ? 1 : n_slices;
+    a.radius = cfg.radius; a.unit = cfg.unit;
+    a.large_units = (uint32_t)std::lround((double)cfg.large / (double)cfg.unit);
+    a.atomic_out = a.n_slices > 1;
+    const bool w64 = cfg.word64 != 0;
+    switch (guided_radius) {
+        case 1: return w64 ? launch_fast_t<1, true>(a, s) : launch_fast_t<1, false>(a, s);
+        case 2: return w64 ? launch_fast_t<2, true>(a, s) : launch_fast_t<2, false>(a, s);
+        case 3: return w64 ? launch_fast_t<3, true>(a, s) : launch_fast_t<3, false>(a, s);
+        case 4: return w64 ? launch_fast_t<4, true>(a, s) : launch_fast_t<4, false>(a, s);
+        default: set_error("fast fused guided kernel supports radius 1..4"); return STEREO_EUNSUPPORTED;
+    }
+}
+
+}  // namespace shp

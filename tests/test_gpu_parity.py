@@ -367,3 +367,21 @@ def test_radius8_filters_fused_golden(oracle):
     lay = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_BILATERAL, 0, 1.0, want_layers=True)[2]
     d, c = stereo.compute_disparity(left, right, 12, wct_radius=8, filter_type="bilateral", show_progress=False)
     assert_wta_matches(d, c, g["disp_bilateral"], g["cost_bilateral"], lay, min_agree=0.95)
+
+
+def test_fast_and_general_fused_kernels_agree():
+    """The fast fused kernel (32-bit lane-shift box sums) against the general one (float64 sums
+    exchanged through LDS) on the same input: costs within 1e-6, disparities equal except near-ties."""
+    import _native
+    import stereo
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(150, 333, 70, seed=33)
+    lib = _native.lib()
+    try:
+        _native.check(lib.stereo_debug_force_general_kernel(1))
+        d_gen, c_gen = stereo.compute_disparity(left, right, 70, guided_eps=0.0154, show_progress=False)
+    finally:
+        _native.check(lib.stereo_debug_force_general_kernel(0))
+    d_fast, c_fast = stereo.compute_disparity(left, right, 70, guided_eps=0.0154, show_progress=False)
+    assert rel_err(c_fast, c_gen) <= 1e-6
+    assert np.mean(d_fast == d_gen) >= 0.9995
