@@ -53,26 +53,36 @@ __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
-template <int RG, bool WORD64, int TH, int NW>
+// order-preserving key of a float32 that is not NaN
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+
+template <int RG, bool WORD64, int TH, int NW, bool QOUT>
 __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) {
     constexpr int WIN = 2 * RG + 1;
     constexpr int HALO = 2 * RG;
     constexpr int NI = TH + 4 * RG;
     constexpr int NJ = TH + 2 * RG;
     constexpr int TWV = 64 - 4 * RG;
+    static_assert(NI % WIN == 0, "the row loop is unrolled by the window length without a tail");
     using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char *sp = smem_raw;
     double *mG_s = reinterpret_cast<double *>(sp); sp += sizeof(double) * NJ * 64;
     uint64_t *key_s = reinterpret_cast<uint64_t *>(sp); sp += sizeof(uint64_t) * TH * 64;
+    double *iay1_s = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((NJ + 1) / 2 * 2);  // 1/rows in window, stage 1
+    double *iay2_s = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((TH + 1) / 2 * 2);  // same for the output rows
     double *invtab = reinterpret_cast<double *>(sp); sp += sizeof(double) * 16;
     WordT *L_s = reinterpret_cast<WordT *>(sp); sp += sizeof(WordT) * NI * 64;
     float *inv_s = reinterpret_cast<float *>(sp); sp += sizeof(float) * NJ * 64;
     float *G_s = reinterpret_cast<float *>(sp); sp += sizeof(float) * NI * 64;
+    int *next_d = reinterpret_cast<int *>(sp); sp += 16;
     short *k_s = reinterpret_cast<short *>(sp);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int H = a.H, W = a.W;
     const int tx0 = blockIdx.x * TWV, ty0 = blockIdx.y * TH;
     const WordT *lw = static_cast<const WordT *>(a.lw);
@@ -105,7 +115,18 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
         inv_s[idx] = in ? (float)a.invden[(size_t)gy * W + gx] : 0.f;
     }
     for (int idx = threadIdx.x; idx < TH * 64; idx += NW * 64) key_s[idx] = SHP_KEY_INIT;
+    // reciprocal of the clipped window height per row; 0 for rows outside the image, which
+    // zeroes a and b there without a branch
+    for (int j = threadIdx.x; j < NJ; j += NW * 64) {
+        int y = ty0 - RG + j;
+        iay1_s[j] = (y >= 0 && y < H) ? 1.0 / (double)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.0;
+    }
+    for (int o = threadIdx.x; o < TH; o += NW * 64) {
+        int y = ty0 + o;
+        iay2_s[o] = (y < H) ? 1.0 / (double)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.0;
+    }
     if (threadIdx.x <= WIN) invtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
+    if (threadIdx.x == 0) *next_d = 0;
     __syncthreads();
 
     const int x = tx0 - HALO + lane;   // column of this lane's cost and of its final output
@@ -114,16 +135,27 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     const bool x1_in = x1 >= 0 && x1 < W && lane >= RG;
     const int cx = x_in ? (min(x + RG, W - 1) - max(x - RG, 0) + 1) : 0;
     const int cx1 = x1_in ? (min(x1 + RG, W - 1) - max(x1 - RG, 0) + 1) : 0;
-    const double invAX1 = invtab[cx1];
+    const double invAX1 = invtab[cx1];                   // 0 when column x1 is outside the image
     const double invAX2 = invtab[cx] * (double)a.unit;
     const int R = a.radius;
     const bool x_valid = x_in && x >= R && x < W - R;
     const bool out_lane = lane >= HALO && lane < 64 - HALO && x < W;
     const uint32_t large_u = a.large_units;
+    const int lane1 = max(lane - RG, 0);
+    // rows of the tile whose census centre is valid / which are inside the image, as tile-row ranges
+    const int iv_lo = max(R - (ty0 - HALO), 0), iv_hi = min(H - R - (ty0 - HALO), NI);  // valid: iv_lo <= i < iv_hi
+    const int ii_lo = max(-(ty0 - HALO), 0), ii_hi = min(H - (ty0 - HALO), NI);          // inside: ii_lo <= i < ii_hi
+    const int o_hi = min(H - ty0, TH);
+    const int n_disp = a.d_end - a.d_begin;
 
-    // disparities of this slice, dealt to the wavefronts round-robin
-    const int slice = blockIdx.z;
-    for (int d = a.d_begin + slice * NW + wave; d < a.d_end; d += NW * a.n_slices) {
+    // disparities are handed to the wavefronts of the workgroup one at a time
+    for (;;) {
+        int dn = 0;
+        if (lane == 0) dn = atomicAdd(next_d, 1);
+        dn = __builtin_amdgcn_readfirstlane(dn);
+        const int d = a.d_begin + dn * a.n_slices + (int)blockIdx.z;
+        if (d >= a.d_end || dn >= n_disp) break;
+
         uint32_t C1 = 0u;
         int I2 = 0;
         float F2 = 0.f;
@@ -132,102 +164,88 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
         int kr[WIN];
         float gr[WIN];
         double ar[WIN], br[WIN];
-        WordT rcur[WIN], rnext[WIN];
+        WordT rwd[WIN];
 #pragma unroll
         for (int k = 0; k < WIN; ++k) { pr[k] = 0u; kr[k] = 0; gr[k] = 0.f; ar[k] = 0.0; br[k] = 0.0; }
         const bool xd_valid = x_valid && (x - d >= R);
-        const size_t xr = (size_t)(x - d);
-        // right census words of the first row group
+        // element offset of the right census word of tile row 0; rows outside [iv_lo, iv_hi) are never loaded
+        const int roff0 = (ty0 - HALO) * W + (x - d);
+        // (positions that are not valid read word 0 instead of branching: the value is unused)
 #pragma unroll
-        for (int k = 0; k < WIN; ++k) {
-            const int yi = ty0 - HALO + k;
-            rnext[k] = (xd_valid && yi >= R && yi < H - R) ? rw[(size_t)yi * W + xr] : WordT(0);
-        }
+        for (int k = 0; k < WIN; ++k) rwd[k] = rw[(xd_valid && k >= iv_lo && k < iv_hi) ? roff0 + k * W : 0];
 
         for (int base = 0; base < NI; base += WIN) {
 #pragma unroll
-            for (int k = 0; k < WIN; ++k) rcur[k] = rnext[k];
-            if (base + WIN < NI) {
-#pragma unroll
-                for (int k = 0; k < WIN; ++k) {
-                    const int yi = ty0 - HALO + base + WIN + k;
-                    rnext[k] = (xd_valid && yi >= R && yi < H - R && base + WIN + k < NI) ? rw[(size_t)yi * W + xr]
-                                                                                         : WordT(0);
-                }
-            }
-#pragma unroll
             for (int k = 0; k < WIN; ++k) {
                 const int i = base + k;
-                if (i < NI) {
-                    const int yi = ty0 - HALO + i;
-                    const bool row_in = yi >= 0 && yi < H;
-                    // 1. cost in units; k*p and g_lo*p
-                    const bool valid = xd_valid && yi >= R && yi < H - R;
-                    uint32_t p = valid ? field_sum((WordT)(L_s[i * 64 + lane] ^ rcur[k])) : large_u;
-                    p = (row_in && x_in) ? p : 0u;
-                    const int kk = (int)k_s[i * 64 + lane];
-                    const float g = G_s[i * 64 + lane];
-                    const float glo = fmaf(-(float)kk, inv_scale_f, g);
-                    const int kp = __mul24(kk, (int)p);
-                    const float gl = glo * (float)p;
-                    // 2. vertical running sums over rows [i - 2r, i]
-                    C1 += p - pr[k];
-                    I2 += kp - kr[k];
-                    F2 += gl - gr[k];
-                    pr[k] = p; kr[k] = kp; gr[k] = gl;
-                    if (i >= HALO) {
-                        // 3. sums over lanes [l - 2r, l]: the box sums of column x1 = x - r
-                        uint32_t s1 = C1;
-                        int si = I2;
-                        float sf = F2;
+                // 1. cost in units; k*p and g_lo*p
+                const bool rowv = i >= iv_lo && i < iv_hi;
+                const bool rowi = i >= ii_lo && i < ii_hi;
+                const uint32_t fs = field_sum((WordT)(L_s[i * 64 + lane] ^ rwd[k]));
+                uint32_t p = (rowv && xd_valid) ? fs : large_u;
+                p = (rowi && x_in) ? p : 0u;
+                // the word of the same ring slot one group ahead
+                {
+                    const int in = i + WIN;
+                    rwd[k] = rw[(xd_valid && in >= iv_lo && in < iv_hi) ? roff0 + in * W : 0];
+                }
+                const int kk = (int)k_s[i * 64 + lane];
+                const float g = G_s[i * 64 + lane];
+                const float glo = fmaf(-(float)kk, inv_scale_f, g);
+                const int kp = __mul24(kk, (int)p);
+                const float gl = glo * (float)p;
+                // 2. vertical running sums over rows [i - 2r, i]
+                C1 += p - pr[k];
+                I2 += kp - kr[k];
+                F2 += gl - gr[k];
+                pr[k] = p; kr[k] = kp; gr[k] = gl;
+                if (i >= HALO) {
+                    // 3. sums over lanes [l - 2r, l]: the box sums of column x1 = x - r
+                    uint32_t s1 = C1;
+                    int si = I2;
+                    float sf = F2;
+#pragma unroll
+                    for (int t = 0; t < 2 * RG; ++t) {
+                        s1 = C1 + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)s1);
+                        si = I2 + dpp_i<DPP_WAVE_SHR1>(si);
+                        sf = F2 + dpp_f<DPP_WAVE_SHR1>(sf);
+                    }
+                    // 4. a, b at (row ty0 - r + j, column x1); 1/area is 0 outside the image
+                    const int j = i - HALO;
+                    const double ia = iay1_s[j] * invAX1;
+                    const double mP = (double)s1 * ia;
+                    const double mGP = fma((double)si, inv_scale_d, (double)sf) * ia;
+                    const double mG = mG_s[j * 64 + lane1];
+                    const double cov = mGP - mG * mP;
+                    const double av = cov * (double)inv_s[j * 64 + lane1];
+                    const double bv = mP - av * mG;
+                    // 5. vertical running sums over stage-1 rows [j - 2r, j]
+                    const int k2 = (k + 1) % WIN;
+                    A += av - ar[k2];
+                    B += bv - br[k2];
+                    ar[k2] = av;
+                    br[k2] = bv;
+                    if (i >= 2 * HALO) {
+                        // 6. sums over lanes [l, l + 2r] (stage-1 columns x - r .. x + r)
+                        const int o = i - 2 * HALO;
+                        const float gout = G_s[(o + HALO) * 64 + lane];
+                        const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gout), 32));
+                        const float ef = (float)fma(A, (double)c0, B);
+                        const float af = (float)A;
+                        float se = ef, sa = af;
 #pragma unroll
                         for (int t = 0; t < 2 * RG; ++t) {
-                            s1 = C1 + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)s1);
-                            si = I2 + dpp_i<DPP_WAVE_SHR1>(si);
-                            sf = F2 + dpp_f<DPP_WAVE_SHR1>(sf);
+                            se = ef + dpp_f<DPP_WAVE_SHL1>(se);
+                            sa = af + dpp_f<DPP_WAVE_SHL1>(sa);
                         }
-                        // 4. a, b at (row ty0 - r + j, column x1)
-                        const int j = i - HALO;
-                        const int ym = ty0 - RG + j;
-                        double av = 0.0, bv = 0.0;
-                        if (ym >= 0 && ym < H && x1_in) {
-                            const int cy = min(ym + RG, H - 1) - max(ym - RG, 0) + 1;
-                            const double ia = invtab[cy] * invAX1;
-                            const double mP = (double)s1 * ia;
-                            const double mGP = fma((double)si, inv_scale_d, (double)sf) * ia;
-                            const double mG = mG_s[j * 64 + lane - RG];
-                            const double cov = mGP - mG * mP;
-                            av = cov * (double)inv_s[j * 64 + lane - RG];
-                            bv = mP - av * mG;
-                        }
-                        // 5. vertical running sums over stage-1 rows [j - 2r, j]
-                        const int k2 = (k + 1) % WIN;
-                        A += av - ar[k2];
-                        B += bv - br[k2];
-                        ar[k2] = av;
-                        br[k2] = bv;
-                        if (i >= 2 * HALO) {
-                            // 6. sums over lanes [l, l + 2r] (stage-1 columns x - r .. x + r)
-                            const int o = i - 2 * HALO;
-                            const int yo = ty0 + o;
-                            const float gout = G_s[(o + HALO) * 64 + lane];
-                            const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gout), 32));
-                            const float ef = (float)fma(A, (double)c0, B);
-                            const float af = (float)A;
-                            float se = ef, sa = af;
-#pragma unroll
-                            for (int t = 0; t < 2 * RG; ++t) {
-                                se = ef + dpp_f<DPP_WAVE_SHL1>(se);
-                                sa = af + dpp_f<DPP_WAVE_SHL1>(sa);
-                            }
-                            // 7. q and the running WTA
-                            if (out_lane && yo < H) {
-                                const int cy = min(yo + RG, H - 1) - max(yo - RG, 0) + 1;
-                                const float t32 = fmaf(gout - c0, sa, se);
-                                const float qf = (float)((double)t32 * (invtab[cy] * invAX2));
-                                if (a.q_out) a.q_out[((size_t)d * H + yo) * W + x] = qf;
-                                if (qf == qf) atomicMin(reinterpret_cast<unsigned long long *>(&key_s[o * 64 + lane]),
-                                                        (unsigned long long)make_key(qf, (uint32_t)d));
+                        // 7. q and the running WTA
+                        const float t32 = fmaf(gout - c0, sa, se);
+                        const float qf = (float)((double)t32 * (iay2_s[o] * invAX2));
+                        if (out_lane && o < o_hi) {
+                            if (QOUT) a.q_out[((size_t)d * H + (ty0 + o)) * W + x] = qf;
+                            if (qf == qf) {
+                                const unsigned long long key = ((unsigned long long)ordered_bits(qf) << 32) | (uint32_t)d;
+                                atomicMin(reinterpret_cast<unsigned long long *>(&key_s[o * 64 + lane]), key);
                             }
                         }
                     }
@@ -248,22 +266,33 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     }
 }
 
-constexpr int FF_TH = 64;
+// tile height per guided radius: TH + 4r must be a multiple of 2r + 1
+template <int RG> struct FastTile;
+template <> struct FastTile<1> { static constexpr int TH = 65; };
+template <> struct FastTile<2> { static constexpr int TH = 67; };
+template <> struct FastTile<3> { static constexpr int TH = 65; };
+template <> struct FastTile<4> { static constexpr int TH = 65; };
 constexpr int FF_NW = 16;
 
-template <int RG, bool WORD64>
-static int launch_fast_t(const FastArgs &a, hipStream_t s) {
-    constexpr int NI = FF_TH + 4 * RG, NJ = FF_TH + 2 * RG, TWV = 64 - 4 * RG;
+template <int RG, bool WORD64, bool QOUT>
+static int launch_fast_q(const FastArgs &a, hipStream_t s) {
+    constexpr int TH = FastTile<RG>::TH;
+    constexpr int NI = TH + 4 * RG, NJ = TH + 2 * RG, TWV = 64 - 4 * RG;
     using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
-    size_t smem = sizeof(double) * NJ * 64 + sizeof(uint64_t) * FF_TH * 64 + sizeof(double) * 16 +
-                  sizeof(WordT) * NI * 64 + sizeof(float) * NJ * 64 + sizeof(float) * NI * 64 + sizeof(short) * NI * 64;
-    auto kern = fused_guided_fast_kernel<RG, WORD64, FF_TH, FF_NW>;
+    size_t smem = sizeof(double) * NJ * 64 + sizeof(uint64_t) * TH * 64 + sizeof(double) * ((NJ + 1) / 2 * 2) +
+                  sizeof(double) * ((TH + 1) / 2 * 2) + sizeof(double) * 16 + sizeof(WordT) * NI * 64 +
+                  sizeof(float) * NJ * 64 + sizeof(float) * NI * 64 + 16 + sizeof(short) * NI * 64;
+    auto kern = fused_guided_fast_kernel<RG, WORD64, TH, FF_NW, QOUT>;
     SHP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
-    dim3 grid(ceil_div(a.W, TWV), ceil_div(a.H, FF_TH), a.n_slices);
+    dim3 grid(ceil_div(a.W, TWV), ceil_div(a.H, TH), a.n_slices);
     hipLaunchKernelGGL(kern, grid, dim3(FF_NW * 64), smem, s, a);
     SHP_LAUNCH_CHECK();
     return STEREO_OK;
+}
+template <int RG, bool WORD64>
+static int launch_fast_t(const FastArgs &a, hipStream_t s) {
+    return a.q_out ? launch_fast_q<RG, WORD64, true>(a, s) : launch_fast_q<RG, WORD64, false>(a, s);
 }
 
 bool fused_fast_supported(const CensusCfg &cfg, int guided_radius) {
@@ -272,9 +301,9 @@ bool fused_fast_supported(const CensusCfg &cfg, int guided_radius) {
 
 // Number of disparity slices (gridDim.z) that gives the chip enough workgroups.
 int fused_fast_slices(int H, int W, int guided_radius, int n_disp) {
-    int tiles = ceil_div(W, 64 - 4 * guided_radius) * ceil_div(H, FF_TH);
+    int tiles = ceil_div(W, 64 - 4 * guided_radius) * ceil_div(H, 65);
     int s = 1;
-    while (tiles * s < 2048 && s * FF_NW * 2 <= n_disp) s *= 2;
+    while (tiles * s < 2048 && s * FF_NW * 4 <= n_disp) s *= 2;
     return s;
 }
 
