@@ -10,11 +10,14 @@
 //    The three 32-bit running sums are summed across 2r+1 neighbouring lanes with a chain of
 //    v_add_*_dpp wave_shr:1 instructions (s_t = v + shift(s_{t-1})).
 //  * a, b and their vertical running sums stay float64 as in the reference.
-//  * Stage 2 (box sums of a and b) is reduced to two float32 chains: with c0 the guide value
-//    of the wavefront's centre lane, box(a)*G + box(b) = sum(E) + (G - c0) * sum(A) where
-//    E = A*c0 + B carries no cancellation (it is the filter output for a guide equal to c0),
-//    so float32 is enough for E and for A (which is multiplied by the small G - c0).
-//    The chain runs the other way (wave_shl:1) so outputs land back on their own lane.
+//  * Stage 2 (box sums of a and b) avoids summing the ill-conditioned pair (sum a, sum b) across
+//    lanes.  With A_j, B_j the vertical sums of column j and G_j the guide of column j in the
+//    output row:  sum_j (A_j*G(x) + B_j) = sum_j E_j + sum_j A_j*(G(x) - G_j),  E_j = A_j*G_j + B_j.
+//    E_j is the (7-row) filter output column j would get from its own guide value: no
+//    cancellation, so a float32 lane chain suffices.  The second sum is evaluated term by term
+//    (A_j shifted across lanes, guide differences from LDS); each term is small and
+//    well-conditioned, so float32 suffices there as well.  The chains run the other way
+//    (wave_shl:1) so that outputs land back on their own lane.
 //  * The final scaling by 1/area is done in float64 so that a constant window returns the
 //    constant exactly (ties between all-`large` layers must stay ties).
 #include <type_traits>
@@ -59,6 +62,143 @@ __device__ __forceinline__ uint32_t ordered_bits(float f) {
     return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
 }
 
+// LDS image of one tile (pointers into the dynamic shared segment)
+template <typename WordT>
+struct TileLds {
+    double *mG;      // [NJ][64] box mean of the guide
+    uint64_t *key;   // [TH][64] packed (cost, d); every lane owns a slot, only the inner ones are written out
+    double *iay1;    // [NJ] 1 / (rows of the clipped window), 0 outside the image
+    double *iay2;    // [TH] same for the output rows
+    double *invtab;  // [16] 1/n
+    WordT *L;        // [NI][64] left census words
+    float *inv;      // [NJ][64] 1 / (var + eps)
+    float *glo;      // [NI][64] guide - k * 2^-s
+    float *gout;     // [TH][64] (+pad) guide at the output pixels
+    int *next_d;
+    short *k;        // [NI][64] round(guide * 2^s)
+};
+
+// One disparity of one tile.  INTERIOR: every row the tile touches is inside the image and has a
+// valid census centre, so the per-row tests vanish.
+template <int RG, bool WORD64, int TH, bool QOUT, bool INTERIOR>
+__device__ __forceinline__ void fast_disparity_pass(
+    const FastArgs &a, const TileLds<typename std::conditional<WORD64, uint64_t, uint32_t>::type> &t, const int d,
+    const int lane, const int x, const int ty0, const bool x_in, const bool x_valid, const double invAX1,
+    const double invAX2, const int lane1, const double inv_scale_d) {
+    constexpr int WIN = 2 * RG + 1;
+    constexpr int HALO = 2 * RG;
+    constexpr int NI = TH + 4 * RG;
+    using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
+    const int H = a.H, W = a.W, R = a.radius;
+    const WordT *rw = static_cast<const WordT *>(a.rw);
+    const uint32_t large_lane = x_in ? a.large_units : 0u;  // cost of an invalid pixel; 0 outside the image
+    // tile-row ranges: census centre valid for iv_lo <= i < iv_hi, row inside the image for ii_lo <= i < ii_hi
+    const int iv_lo = max(R - (ty0 - HALO), 0), iv_hi = min(H - R - (ty0 - HALO), NI);
+    const int ii_lo = max(-(ty0 - HALO), 0), ii_hi = min(H - (ty0 - HALO), NI);
+
+    uint32_t C1 = 0u;
+    int I2 = 0;
+    float F2 = 0.f;
+    double A = 0.0, B = 0.0;
+    uint32_t pr[WIN];
+    int kr[WIN];
+    float gr[WIN];
+    double ar[WIN], br[WIN];
+    WordT rwd[WIN];
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) { pr[k] = 0u; kr[k] = 0; gr[k] = 0.f; ar[k] = 0.0; br[k] = 0.0; }
+    const bool xd_valid = x_valid && (x - d >= R);
+    // Right census words: lanes without a valid match read a clamped in-range column (value unused).
+    const int xr = min(max(x - d, 0), W - 1);
+    const WordT *rp = rw + xr;
+    auto row_of = [&](int i) -> int {  // image row of tile row i, clamped into the image on border tiles
+        int y = ty0 - HALO + i;
+        return INTERIOR ? y : min(max(y, 0), H - 1);
+    };
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) rwd[k] = rp[(size_t)row_of(k) * W];
+
+    for (int base = 0; base < NI; base += WIN) {
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const int i = base + k;
+            // 1. cost in units; k*p and g_lo*p
+            const uint32_t fs = field_sum((WordT)(t.L[i * 64 + lane] ^ rwd[k]));
+            uint32_t p;
+            if (INTERIOR) {
+                p = xd_valid ? fs : large_lane;
+            } else {
+                const bool rowv = i >= iv_lo && i < iv_hi;
+                const bool rowi = i >= ii_lo && i < ii_hi;
+                p = (rowv && xd_valid) ? fs : large_lane;
+                p = rowi ? p : 0u;
+            }
+            if (base + WIN < NI) rwd[k] = rp[(size_t)row_of(i + WIN) * W];  // same ring slot, next group
+            const int kk = (int)t.k[i * 64 + lane];
+            const float glo = t.glo[i * 64 + lane];
+            const int kp = __mul24(kk, (int)p);
+            const float gl = glo * (float)p;
+            // 2. vertical running sums over rows [i - 2r, i]
+            C1 += p - pr[k];
+            I2 += kp - kr[k];
+            F2 += gl - gr[k];
+            pr[k] = p; kr[k] = kp; gr[k] = gl;
+            if (i >= HALO) {
+                // 3. sums over lanes [l - 2r, l]: the box sums of column x - r
+                uint32_t s1 = C1;
+                int si = I2;
+                float sf = F2;
+#pragma unroll
+                for (int u = 0; u < 2 * RG; ++u) {
+                    s1 = C1 + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)s1);
+                    si = I2 + dpp_i<DPP_WAVE_SHR1>(si);
+                    sf = F2 + dpp_f<DPP_WAVE_SHR1>(sf);
+                }
+                // 4. a, b at (row ty0 - r + j, column x - r); 1/area is 0 outside the image
+                const int j = i - HALO;
+                const double ia = t.iay1[j] * invAX1;
+                const double mP = (double)s1 * ia;
+                const double mGP = fma((double)si, inv_scale_d, (double)sf) * ia;
+                const double mG = t.mG[j * 64 + lane1];
+                const double cov = mGP - mG * mP;
+                const double av = cov * (double)t.inv[j * 64 + lane1];
+                const double bv = mP - av * mG;
+                // 5. vertical running sums over stage-1 rows [j - 2r, j]
+                const int k2 = (k + 1) % WIN;
+                A += av - ar[k2];
+                B += bv - br[k2];
+                ar[k2] = av;
+                br[k2] = bv;
+                if (i >= 2 * HALO) {
+                    // 6. sums over lanes [l, l + 2r] (stage-1 columns x - r .. x + r)
+                    const int o = i - 2 * HALO;
+                    const float *grow = t.gout + o * 64 + lane;
+                    const float gx = grow[0];
+                    const float ef = (float)fma(A, (double)gx, B);  // column's own-guide output (7 rows)
+                    float ash = (float)A;
+                    float se = ef, dsum = 0.f;
+#pragma unroll
+                    for (int u = 1; u <= 2 * RG; ++u) {
+                        se = ef + dpp_f<DPP_WAVE_SHL1>(se);
+                        ash = dpp_f<DPP_WAVE_SHL1>(ash);              // A of column x + u
+                        dsum = fmaf(ash, gx - grow[u], dsum);         // A_j * (G(x) - G_j)
+                    }
+                    // 7. q and the running WTA (NaN never wins: it is replaced by +inf)
+                    const float t32 = se + dsum;
+                    float qf = (float)((double)t32 * (t.iay2[o] * invAX2));
+                    if (QOUT) {
+                        const int yo = ty0 + o;
+                        if (lane >= HALO && lane < 64 - HALO && x < W && yo < H) a.q_out[((size_t)d * H + yo) * W + x] = qf;
+                    }
+                    qf = (qf == qf) ? qf : __int_as_float(0x7f800000);
+                    const unsigned long long key = ((unsigned long long)ordered_bits(qf) << 32) | (uint32_t)d;
+                    atomicMin(reinterpret_cast<unsigned long long *>(&t.key[o * 64 + lane]), key);
+                }
+            }
+        }
+    }
+}
+
 template <int RG, bool WORD64, int TH, int NW, bool QOUT>
 __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) {
     constexpr int WIN = 2 * RG + 1;
@@ -71,22 +211,23 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char *sp = smem_raw;
-    double *mG_s = reinterpret_cast<double *>(sp); sp += sizeof(double) * NJ * 64;
-    uint64_t *key_s = reinterpret_cast<uint64_t *>(sp); sp += sizeof(uint64_t) * TH * 64;
-    double *iay1_s = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((NJ + 1) / 2 * 2);  // 1/rows in window, stage 1
-    double *iay2_s = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((TH + 1) / 2 * 2);  // same for the output rows
-    double *invtab = reinterpret_cast<double *>(sp); sp += sizeof(double) * 16;
-    WordT *L_s = reinterpret_cast<WordT *>(sp); sp += sizeof(WordT) * NI * 64;
-    float *inv_s = reinterpret_cast<float *>(sp); sp += sizeof(float) * NJ * 64;
-    float *G_s = reinterpret_cast<float *>(sp); sp += sizeof(float) * NI * 64;
-    int *next_d = reinterpret_cast<int *>(sp); sp += 16;
-    short *k_s = reinterpret_cast<short *>(sp);
+    TileLds<WordT> t;
+    t.mG = reinterpret_cast<double *>(sp); sp += sizeof(double) * NJ * 64;
+    t.key = reinterpret_cast<uint64_t *>(sp); sp += sizeof(uint64_t) * TH * 64;
+    t.iay1 = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((NJ + 1) / 2 * 2);
+    t.iay2 = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((TH + 1) / 2 * 2);
+    t.invtab = reinterpret_cast<double *>(sp); sp += sizeof(double) * 16;
+    t.L = reinterpret_cast<WordT *>(sp); sp += sizeof(WordT) * NI * 64;
+    t.inv = reinterpret_cast<float *>(sp); sp += sizeof(float) * NJ * 64;
+    t.glo = reinterpret_cast<float *>(sp); sp += sizeof(float) * NI * 64;
+    t.gout = reinterpret_cast<float *>(sp); sp += sizeof(float) * (TH * 64 + 16);
+    t.next_d = reinterpret_cast<int *>(sp); sp += 16;
+    t.k = reinterpret_cast<short *>(sp);
 
     const int lane = threadIdx.x & 63;
     const int H = a.H, W = a.W;
     const int tx0 = blockIdx.x * TWV, ty0 = blockIdx.y * TH;
     const WordT *lw = static_cast<const WordT *>(a.lw);
-    const WordT *rw = static_cast<const WordT *>(a.rw);
 
     // guide quantisation: |k| <= kmax keeps the (2r+1)^2-window sum of k*p inside int32
     const float gmax = *a.gmax;
@@ -103,30 +244,32 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
         int gy = ty0 - HALO + i, gx = tx0 - HALO + l;
         bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         float g = in ? a.guide[(size_t)gy * W + gx] : 0.f;
-        G_s[idx] = g;
-        k_s[idx] = (short)__float2int_rn(g * scale_f);
-        L_s[idx] = in ? lw[(size_t)gy * W + gx] : WordT(0);
+        int kk = __float2int_rn(g * scale_f);
+        t.k[idx] = (short)kk;
+        t.glo[idx] = fmaf(-(float)kk, inv_scale_f, g);
+        t.L[idx] = in ? lw[(size_t)gy * W + gx] : WordT(0);
+        int o = i - HALO;
+        if (o >= 0 && o < TH) t.gout[o * 64 + l] = g;
     }
     for (int idx = threadIdx.x; idx < NJ * 64; idx += NW * 64) {
         int j = idx >> 6, l = idx & 63;
         int gy = ty0 - RG + j, gx = tx0 - HALO + l;
         bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        mG_s[idx] = in ? a.mean[(size_t)gy * W + gx] : 0.0;
-        inv_s[idx] = in ? (float)a.invden[(size_t)gy * W + gx] : 0.f;
+        t.mG[idx] = in ? a.mean[(size_t)gy * W + gx] : 0.0;
+        t.inv[idx] = in ? (float)a.invden[(size_t)gy * W + gx] : 0.f;
     }
-    for (int idx = threadIdx.x; idx < TH * 64; idx += NW * 64) key_s[idx] = SHP_KEY_INIT;
-    // reciprocal of the clipped window height per row; 0 for rows outside the image, which
-    // zeroes a and b there without a branch
+    for (int idx = threadIdx.x; idx < TH * 64; idx += NW * 64) t.key[idx] = SHP_KEY_INIT;
+    if (threadIdx.x < 16) t.gout[TH * 64 + threadIdx.x] = 0.f;
     for (int j = threadIdx.x; j < NJ; j += NW * 64) {
         int y = ty0 - RG + j;
-        iay1_s[j] = (y >= 0 && y < H) ? 1.0 / (double)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.0;
+        t.iay1[j] = (y >= 0 && y < H) ? 1.0 / (double)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.0;
     }
     for (int o = threadIdx.x; o < TH; o += NW * 64) {
         int y = ty0 + o;
-        iay2_s[o] = (y < H) ? 1.0 / (double)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.0;
+        t.iay2[o] = (y < H) ? 1.0 / (double)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.0;
     }
-    if (threadIdx.x <= WIN) invtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
-    if (threadIdx.x == 0) *next_d = 0;
+    if (threadIdx.x <= WIN) t.invtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
+    if (threadIdx.x == 0) *t.next_d = 0;
     __syncthreads();
 
     const int x = tx0 - HALO + lane;   // column of this lane's cost and of its final output
@@ -135,130 +278,34 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     const bool x1_in = x1 >= 0 && x1 < W && lane >= RG;
     const int cx = x_in ? (min(x + RG, W - 1) - max(x - RG, 0) + 1) : 0;
     const int cx1 = x1_in ? (min(x1 + RG, W - 1) - max(x1 - RG, 0) + 1) : 0;
-    const double invAX1 = invtab[cx1];                   // 0 when column x1 is outside the image
-    const double invAX2 = invtab[cx] * (double)a.unit;
+    const double invAX1 = t.invtab[cx1];                   // 0 when column x1 is outside the image
+    const double invAX2 = t.invtab[cx] * (double)a.unit;
     const int R = a.radius;
     const bool x_valid = x_in && x >= R && x < W - R;
-    const bool out_lane = lane >= HALO && lane < 64 - HALO && x < W;
-    const uint32_t large_u = a.large_units;
     const int lane1 = max(lane - RG, 0);
-    // rows of the tile whose census centre is valid / which are inside the image, as tile-row ranges
-    const int iv_lo = max(R - (ty0 - HALO), 0), iv_hi = min(H - R - (ty0 - HALO), NI);  // valid: iv_lo <= i < iv_hi
-    const int ii_lo = max(-(ty0 - HALO), 0), ii_hi = min(H - (ty0 - HALO), NI);          // inside: ii_lo <= i < ii_hi
-    const int o_hi = min(H - ty0, TH);
+    const bool interior = (ty0 - HALO >= R) && (ty0 + TH + HALO <= H - R);
     const int n_disp = a.d_end - a.d_begin;
 
     // disparities are handed to the wavefronts of the workgroup one at a time
     for (;;) {
         int dn = 0;
-        if (lane == 0) dn = atomicAdd(next_d, 1);
+        if (lane == 0) dn = atomicAdd(t.next_d, 1);
         dn = __builtin_amdgcn_readfirstlane(dn);
         const int d = a.d_begin + dn * a.n_slices + (int)blockIdx.z;
         if (d >= a.d_end || dn >= n_disp) break;
-
-        uint32_t C1 = 0u;
-        int I2 = 0;
-        float F2 = 0.f;
-        double A = 0.0, B = 0.0;
-        uint32_t pr[WIN];
-        int kr[WIN];
-        float gr[WIN];
-        double ar[WIN], br[WIN];
-        WordT rwd[WIN];
-#pragma unroll
-        for (int k = 0; k < WIN; ++k) { pr[k] = 0u; kr[k] = 0; gr[k] = 0.f; ar[k] = 0.0; br[k] = 0.0; }
-        const bool xd_valid = x_valid && (x - d >= R);
-        // element offset of the right census word of tile row 0; rows outside [iv_lo, iv_hi) are never loaded
-        const int roff0 = (ty0 - HALO) * W + (x - d);
-        // (positions that are not valid read word 0 instead of branching: the value is unused)
-#pragma unroll
-        for (int k = 0; k < WIN; ++k) rwd[k] = rw[(xd_valid && k >= iv_lo && k < iv_hi) ? roff0 + k * W : 0];
-
-        for (int base = 0; base < NI; base += WIN) {
-#pragma unroll
-            for (int k = 0; k < WIN; ++k) {
-                const int i = base + k;
-                // 1. cost in units; k*p and g_lo*p
-                const bool rowv = i >= iv_lo && i < iv_hi;
-                const bool rowi = i >= ii_lo && i < ii_hi;
-                const uint32_t fs = field_sum((WordT)(L_s[i * 64 + lane] ^ rwd[k]));
-                uint32_t p = (rowv && xd_valid) ? fs : large_u;
-                p = (rowi && x_in) ? p : 0u;
-                // the word of the same ring slot one group ahead
-                {
-                    const int in = i + WIN;
-                    rwd[k] = rw[(xd_valid && in >= iv_lo && in < iv_hi) ? roff0 + in * W : 0];
-                }
-                const int kk = (int)k_s[i * 64 + lane];
-                const float g = G_s[i * 64 + lane];
-                const float glo = fmaf(-(float)kk, inv_scale_f, g);
-                const int kp = __mul24(kk, (int)p);
-                const float gl = glo * (float)p;
-                // 2. vertical running sums over rows [i - 2r, i]
-                C1 += p - pr[k];
-                I2 += kp - kr[k];
-                F2 += gl - gr[k];
-                pr[k] = p; kr[k] = kp; gr[k] = gl;
-                if (i >= HALO) {
-                    // 3. sums over lanes [l - 2r, l]: the box sums of column x1 = x - r
-                    uint32_t s1 = C1;
-                    int si = I2;
-                    float sf = F2;
-#pragma unroll
-                    for (int t = 0; t < 2 * RG; ++t) {
-                        s1 = C1 + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)s1);
-                        si = I2 + dpp_i<DPP_WAVE_SHR1>(si);
-                        sf = F2 + dpp_f<DPP_WAVE_SHR1>(sf);
-                    }
-                    // 4. a, b at (row ty0 - r + j, column x1); 1/area is 0 outside the image
-                    const int j = i - HALO;
-                    const double ia = iay1_s[j] * invAX1;
-                    const double mP = (double)s1 * ia;
-                    const double mGP = fma((double)si, inv_scale_d, (double)sf) * ia;
-                    const double mG = mG_s[j * 64 + lane1];
-                    const double cov = mGP - mG * mP;
-                    const double av = cov * (double)inv_s[j * 64 + lane1];
-                    const double bv = mP - av * mG;
-                    // 5. vertical running sums over stage-1 rows [j - 2r, j]
-                    const int k2 = (k + 1) % WIN;
-                    A += av - ar[k2];
-                    B += bv - br[k2];
-                    ar[k2] = av;
-                    br[k2] = bv;
-                    if (i >= 2 * HALO) {
-                        // 6. sums over lanes [l, l + 2r] (stage-1 columns x - r .. x + r)
-                        const int o = i - 2 * HALO;
-                        const float gout = G_s[(o + HALO) * 64 + lane];
-                        const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gout), 32));
-                        const float ef = (float)fma(A, (double)c0, B);
-                        const float af = (float)A;
-                        float se = ef, sa = af;
-#pragma unroll
-                        for (int t = 0; t < 2 * RG; ++t) {
-                            se = ef + dpp_f<DPP_WAVE_SHL1>(se);
-                            sa = af + dpp_f<DPP_WAVE_SHL1>(sa);
-                        }
-                        // 7. q and the running WTA
-                        const float t32 = fmaf(gout - c0, sa, se);
-                        const float qf = (float)((double)t32 * (iay2_s[o] * invAX2));
-                        if (out_lane && o < o_hi) {
-                            if (QOUT) a.q_out[((size_t)d * H + (ty0 + o)) * W + x] = qf;
-                            if (qf == qf) {
-                                const unsigned long long key = ((unsigned long long)ordered_bits(qf) << 32) | (uint32_t)d;
-                                atomicMin(reinterpret_cast<unsigned long long *>(&key_s[o * 64 + lane]), key);
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        if (interior)
+            fast_disparity_pass<RG, WORD64, TH, QOUT, true>(a, t, d, lane, x, ty0, x_in, x_valid, invAX1, invAX2, lane1,
+                                                            inv_scale_d);
+        else
+            fast_disparity_pass<RG, WORD64, TH, QOUT, false>(a, t, d, lane, x, ty0, x_in, x_valid, invAX1, invAX2, lane1,
+                                                             inv_scale_d);
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < TH * 64; idx += NW * 64) {
         int o = idx >> 6, l = idx & 63;
         int gy = ty0 + o, gx = tx0 - HALO + l;
         if (l >= HALO && l < 64 - HALO && gy < H && gx < W) {
-            uint64_t key = key_s[idx];
+            uint64_t key = t.key[idx];
             if (a.atomic_out) atomicMin(reinterpret_cast<unsigned long long *>(&a.keys[(size_t)gy * W + gx]),
                                         (unsigned long long)key);
             else a.keys[(size_t)gy * W + gx] = key;
@@ -266,22 +313,29 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     }
 }
 
-// tile height per guided radius: TH + 4r must be a multiple of 2r + 1
-template <int RG> struct FastTile;
-template <> struct FastTile<1> { static constexpr int TH = 65; };
-template <> struct FastTile<2> { static constexpr int TH = 67; };
-template <> struct FastTile<3> { static constexpr int TH = 65; };
-template <> struct FastTile<4> { static constexpr int TH = 65; };
+// tile height per (guided radius, census word size): TH + 4r is a multiple of 2r + 1 and the
+// tile image fits the 160 KiB LDS
+template <int RG, bool WORD64> struct FastTile;
+template <> struct FastTile<1, false> { static constexpr int TH = 71; };
+template <> struct FastTile<2, false> { static constexpr int TH = 67; };
+template <> struct FastTile<3, false> { static constexpr int TH = 65; };
+template <> struct FastTile<4, false> { static constexpr int TH = 65; };
+template <> struct FastTile<1, true> { static constexpr int TH = 62; };
+template <> struct FastTile<2, true> { static constexpr int TH = 62; };
+template <> struct FastTile<3, true> { static constexpr int TH = 58; };
+template <> struct FastTile<4, true> { static constexpr int TH = 56; };
 constexpr int FF_NW = 16;
 
 template <int RG, bool WORD64, bool QOUT>
 static int launch_fast_q(const FastArgs &a, hipStream_t s) {
-    constexpr int TH = FastTile<RG>::TH;
+    constexpr int TH = FastTile<RG, WORD64>::TH;
     constexpr int NI = TH + 4 * RG, NJ = TH + 2 * RG, TWV = 64 - 4 * RG;
     using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
-    size_t smem = sizeof(double) * NJ * 64 + sizeof(uint64_t) * TH * 64 + sizeof(double) * ((NJ + 1) / 2 * 2) +
-                  sizeof(double) * ((TH + 1) / 2 * 2) + sizeof(double) * 16 + sizeof(WordT) * NI * 64 +
-                  sizeof(float) * NJ * 64 + sizeof(float) * NI * 64 + 16 + sizeof(short) * NI * 64;
+    constexpr size_t smem = sizeof(double) * NJ * 64 + sizeof(uint64_t) * TH * 64 + sizeof(double) * ((NJ + 1) / 2 * 2) +
+                            sizeof(double) * ((TH + 1) / 2 * 2) + sizeof(double) * 16 + sizeof(WordT) * NI * 64 +
+                            sizeof(float) * NJ * 64 + sizeof(float) * NI * 64 + sizeof(float) * (TH * 64 + 16) + 16 +
+                            sizeof(short) * NI * 64;
+    static_assert(smem <= 160 * 1024, "tile image exceeds the LDS");
     auto kern = fused_guided_fast_kernel<RG, WORD64, TH, FF_NW, QOUT>;
     SHP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));

@@ -385,3 +385,25 @@ def test_fast_and_general_fused_kernels_agree():
     d_fast, c_fast = stereo.compute_disparity(left, right, 70, guided_eps=0.0154, show_progress=False)
     assert rel_err(c_fast, c_gen) <= 1e-6
     assert np.mean(d_fast == d_gen) >= 0.9995
+
+
+@pytest.mark.parametrize("scale", [1.0, 255.0, 1.0 / 255.0, 4096.0])
+def test_fused_guided_conditioning(oracle, scale):
+    """Guides with strong edges next to flat areas and different dynamic ranges: the filtered
+    costs stay within tolerance where a = cov/(var + eps) is large and the matching cost is small."""
+    import stereo
+    rng = np.random.default_rng(77)
+    h, w, dmax = 90, 200, 20
+    base = np.zeros((h, w + dmax), dtype=np.float64)
+    base[:, : (w + dmax) // 3] = 20.0
+    base[:, (w + dmax) // 3: 2 * (w + dmax) // 3] = 220.0
+    base[:, 2 * (w + dmax) // 3:] = 90.0
+    base[h // 2:, :] += 15.0
+    base += rng.integers(-2, 3, size=base.shape)
+    tex = np.clip(base, 0, 255)
+    left = (tex[:, :w] * scale).astype(np.float32)
+    right = (tex[:, 7: 7 + w] * scale).astype(np.float32)
+    dsi = oracle.wct_cost_volume(left, right, dmax)
+    dref, cref, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, 3, 0.0154, want_layers=True)
+    d, c = stereo.compute_disparity(left, right, dmax, guided_eps=0.0154, show_progress=False)
+    assert_wta_matches(d, c, dref, cref, layers, min_agree=0.99)
