@@ -20,6 +20,7 @@
 //    (wave_shl:1) so that outputs land back on their own lane.
 //  * The final scaling by 1/area is done in float64 so that a constant window returns the
 //    constant exactly (ties between all-`large` layers must stay ties).
+#include <cstdlib>
 #include <type_traits>
 
 #include "census_dev.hpp"
@@ -56,6 +57,22 @@ __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
+// LDS pointer whose value the optimiser cannot see through: accesses relative to it keep their
+// small row offsets as instruction immediates instead of re-adding the (> 64 KiB) array base.
+#define LDS_AS __attribute__((address_space(3)))
+template <typename T>
+__device__ __forceinline__ LDS_AS T *lds_lane_ptr(T *generic) {
+    unsigned addr = (unsigned)(size_t)(LDS_AS T *)generic;
+    asm volatile("" : "+v"(addr));
+    return (LDS_AS T *)(size_t)addr;
+}
+
+// pure lane shift (no accumulate): lanes without a source read 0
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 // order-preserving key of a float32 that is not NaN
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
     const uint32_t b = __float_as_uint(f);
@@ -68,10 +85,10 @@ struct TileLds {
     double *mG;      // [NJ][64] box mean of the guide
     uint64_t *key;   // [TH][64] packed (cost, d); every lane owns a slot, only the inner ones are written out
     double *iay1;    // [NJ] 1 / (rows of the clipped window), 0 outside the image
-    double *iay2;    // [TH] same for the output rows
+    float *cy2;      // [TH] rows of the clipped window of the output rows (0 outside the image)
     double *invtab;  // [16] 1/n
     WordT *L;        // [NI][64] left census words
-    float *inv;      // [NJ][64] 1 / (var + eps)
+    float *inv;      // [NJ][64] 1 / ((var + eps) * window area)
     float *glo;      // [NI][64] guide - k * 2^-s
     float *gout;     // [TH][64] (+pad) guide at the output pixels
     int *next_d;
@@ -84,7 +101,7 @@ template <int RG, bool WORD64, int TH, bool QOUT, bool INTERIOR>
 __device__ __forceinline__ void fast_disparity_pass(
     const FastArgs &a, const TileLds<typename std::conditional<WORD64, uint64_t, uint32_t>::type> &t, const int d,
     const int lane, const int x, const int ty0, const bool x_in, const bool x_valid, const double invAX1,
-    const double invAX2, const int lane1, const double inv_scale_d) {
+    const float cxf, const int lane1, const double inv_scale_d) {
     constexpr int WIN = 2 * RG + 1;
     constexpr int HALO = 2 * RG;
     constexpr int NI = TH + 4 * RG;
@@ -118,12 +135,29 @@ __device__ __forceinline__ void fast_disparity_pass(
 #pragma unroll
     for (int k = 0; k < WIN; ++k) rwd[k] = rp[(size_t)row_of(k) * W];
 
-    for (int base = 0; base < NI; base += WIN) {
+    const double ia_interior = invAX1 * (1.0 / (double)WIN);
+    const float area_interior = cxf * (float)WIN;
+    const float rcp_interior = __builtin_amdgcn_rcpf(area_interior);
+    // One group of WIN consecutive tile rows.  STEADY groups start at base >= 4r, where both box
+    // stages are live for every row; the first two groups resolve their stage tests at compile
+    // time (base is then the literal 0 or WIN), so no group has a branch in its body.
+    auto row_group = [&](const int base, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        // lane pointers of this group: the per-row accesses below are then immediate offsets
+        LDS_AS const WordT *Lg = lds_lane_ptr(t.L + base * 64 + lane);
+        LDS_AS const short *kg = lds_lane_ptr(t.k + base * 64 + lane);
+        LDS_AS const float *glog = lds_lane_ptr(t.glo + base * 64 + lane);
+        LDS_AS const double *mGg = lds_lane_ptr(t.mG + (base - HALO) * 64 + lane1);
+        LDS_AS const float *invg = lds_lane_ptr(t.inv + (base - HALO) * 64 + lane1);
+        LDS_AS const float *goutg = lds_lane_ptr(t.gout + (base - 2 * HALO) * 64 + lane);
+        LDS_AS uint64_t *keyg = lds_lane_ptr(t.key + (base - 2 * HALO) * 64 + lane);
+        LDS_AS const double *iay1g = lds_lane_ptr(t.iay1 + (base - HALO));
+        LDS_AS const float *cy2g = lds_lane_ptr(t.cy2 + (base - 2 * HALO));
 #pragma unroll
         for (int k = 0; k < WIN; ++k) {
             const int i = base + k;
             // 1. cost in units; k*p and g_lo*p
-            const uint32_t fs = field_sum((WordT)(t.L[i * 64 + lane] ^ rwd[k]));
+            const uint32_t fs = field_sum((WordT)(Lg[k * 64] ^ rwd[k]));
             uint32_t p;
             if (INTERIOR) {
                 p = xd_valid ? fs : large_lane;
@@ -133,9 +167,9 @@ __device__ __forceinline__ void fast_disparity_pass(
                 p = (rowv && xd_valid) ? fs : large_lane;
                 p = rowi ? p : 0u;
             }
-            if (base + WIN < NI) rwd[k] = rp[(size_t)row_of(i + WIN) * W];  // same ring slot, next group
-            const int kk = (int)t.k[i * 64 + lane];
-            const float glo = t.glo[i * 64 + lane];
+            rwd[k] = rp[(size_t)row_of(min(i + WIN, NI - 1)) * W];  // same ring slot, next group
+            const int kk = (int)kg[k * 64];
+            const float glo = glog[k * 64];
             const int kp = __mul24(kk, (int)p);
             const float gl = glo * (float)p;
             // 2. vertical running sums over rows [i - 2r, i]
@@ -143,7 +177,7 @@ __device__ __forceinline__ void fast_disparity_pass(
             I2 += kp - kr[k];
             F2 += gl - gr[k];
             pr[k] = p; kr[k] = kp; gr[k] = gl;
-            if (i >= HALO) {
+            if (STEADY || i >= HALO) {
                 // 3. sums over lanes [l - 2r, l]: the box sums of column x - r
                 uint32_t s1 = C1;
                 int si = I2;
@@ -155,24 +189,23 @@ __device__ __forceinline__ void fast_disparity_pass(
                     sf = F2 + dpp_f<DPP_WAVE_SHR1>(sf);
                 }
                 // 4. a, b at (row ty0 - r + j, column x - r); 1/area is 0 outside the image
-                const int j = i - HALO;
-                const double ia = t.iay1[j] * invAX1;
-                const double mP = (double)s1 * ia;
-                const double mGP = fma((double)si, inv_scale_d, (double)sf) * ia;
-                const double mG = t.mG[j * 64 + lane1];
-                const double cov = mGP - mG * mP;
-                const double av = cov * (double)t.inv[j * 64 + lane1];
-                const double bv = mP - av * mG;
+                //    a = (sum(G p) - mG * sum(p)) / (area * den),  b = sum(p) / area - a * mG
+                const double ia = INTERIOR ? ia_interior : iay1g[k] * invAX1;
+                const double s1d = (double)s1;
+                const double mG = mGg[k * 64];
+                const double u = fma(-mG, s1d, fma((double)si, inv_scale_d, (double)sf));
+                const double av = u * (double)invg[k * 64];
+                const double bv = fma(-av, mG, s1d * ia);
                 // 5. vertical running sums over stage-1 rows [j - 2r, j]
                 const int k2 = (k + 1) % WIN;
                 A += av - ar[k2];
                 B += bv - br[k2];
                 ar[k2] = av;
                 br[k2] = bv;
-                if (i >= 2 * HALO) {
+                if (STEADY || i >= 2 * HALO) {
                     // 6. sums over lanes [l, l + 2r] (stage-1 columns x - r .. x + r)
                     const int o = i - 2 * HALO;
-                    const float *grow = t.gout + o * 64 + lane;
+                    LDS_AS const float *grow = goutg + k * 64;
                     const float gx = grow[0];
                     const float ef = (float)fma(A, (double)gx, B);  // column's own-guide output (7 rows)
                     float ash = (float)A;
@@ -180,23 +213,33 @@ __device__ __forceinline__ void fast_disparity_pass(
 #pragma unroll
                     for (int u = 1; u <= 2 * RG; ++u) {
                         se = ef + dpp_f<DPP_WAVE_SHL1>(se);
-                        ash = dpp_f<DPP_WAVE_SHL1>(ash);              // A of column x + u
+                        ash = dpp_mov_f<DPP_WAVE_SHL1>(ash);          // A of column x + u
                         dsum = fmaf(ash, gx - grow[u], dsum);         // A_j * (G(x) - G_j)
                     }
                     // 7. q and the running WTA (NaN never wins: it is replaced by +inf)
+                    //    t32 / area by one Newton step on the reciprocal: exact whenever the quotient is
+                    //    representable, so a constant window returns the constant (ties stay ties)
                     const float t32 = se + dsum;
-                    float qf = (float)((double)t32 * (t.iay2[o] * invAX2));
+                    const float areaf = INTERIOR ? area_interior : cy2g[k] * cxf;
+                    const float r0 = INTERIOR ? rcp_interior : __builtin_amdgcn_rcpf(areaf);
+                    const float q0 = t32 * r0;
+                    float qf = fmaf(fmaf(-q0, areaf, t32), r0, q0) * a.unit;
                     if (QOUT) {
                         const int yo = ty0 + o;
                         if (lane >= HALO && lane < 64 - HALO && x < W && yo < H) a.q_out[((size_t)d * H + yo) * W + x] = qf;
                     }
                     qf = (qf == qf) ? qf : __int_as_float(0x7f800000);
                     const unsigned long long key = ((unsigned long long)ordered_bits(qf) << 32) | (uint32_t)d;
-                    atomicMin(reinterpret_cast<unsigned long long *>(&t.key[o * 64 + lane]), key);
+                    __hip_atomic_fetch_min(reinterpret_cast<LDS_AS unsigned long long *>(keyg + k * 64), key,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
-    }
+    };
+    static_assert(2 * WIN >= 2 * HALO, "two peeled groups cover the start-up rows");
+    row_group(0, std::false_type{});
+    row_group(WIN, std::false_type{});
+    for (int base = 2 * WIN; base < NI; base += WIN) row_group(base, std::true_type{});
 }
 
 template <int RG, bool WORD64, int TH, int NW, bool QOUT>
@@ -215,7 +258,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     t.mG = reinterpret_cast<double *>(sp); sp += sizeof(double) * NJ * 64;
     t.key = reinterpret_cast<uint64_t *>(sp); sp += sizeof(uint64_t) * TH * 64;
     t.iay1 = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((NJ + 1) / 2 * 2);
-    t.iay2 = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((TH + 1) / 2 * 2);
+    t.cy2 = reinterpret_cast<float *>(sp); sp += sizeof(double) * ((TH + 1) / 2 * 2);
     t.invtab = reinterpret_cast<double *>(sp); sp += sizeof(double) * 16;
     t.L = reinterpret_cast<WordT *>(sp); sp += sizeof(WordT) * NI * 64;
     t.inv = reinterpret_cast<float *>(sp); sp += sizeof(float) * NJ * 64;
@@ -256,7 +299,8 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
         int gy = ty0 - RG + j, gx = tx0 - HALO + l;
         bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         t.mG[idx] = in ? a.mean[(size_t)gy * W + gx] : 0.0;
-        t.inv[idx] = in ? (float)a.invden[(size_t)gy * W + gx] : 0.f;
+        const int cyy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1, cxx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
+        t.inv[idx] = in ? (float)(a.invden[(size_t)gy * W + gx] / (double)(cyy * cxx)) : 0.f;
     }
     for (int idx = threadIdx.x; idx < TH * 64; idx += NW * 64) t.key[idx] = SHP_KEY_INIT;
     if (threadIdx.x < 16) t.gout[TH * 64 + threadIdx.x] = 0.f;
@@ -266,7 +310,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     }
     for (int o = threadIdx.x; o < TH; o += NW * 64) {
         int y = ty0 + o;
-        t.iay2[o] = (y < H) ? 1.0 / (double)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.0;
+        t.cy2[o] = (y < H) ? (float)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.f;
     }
     if (threadIdx.x <= WIN) t.invtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
     if (threadIdx.x == 0) *t.next_d = 0;
@@ -279,7 +323,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     const int cx = x_in ? (min(x + RG, W - 1) - max(x - RG, 0) + 1) : 0;
     const int cx1 = x1_in ? (min(x1 + RG, W - 1) - max(x1 - RG, 0) + 1) : 0;
     const double invAX1 = t.invtab[cx1];                   // 0 when column x1 is outside the image
-    const double invAX2 = t.invtab[cx] * (double)a.unit;
+    const float cxf = (float)cx;
     const int R = a.radius;
     const bool x_valid = x_in && x >= R && x < W - R;
     const int lane1 = max(lane - RG, 0);
@@ -294,10 +338,10 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
         const int d = a.d_begin + dn * a.n_slices + (int)blockIdx.z;
         if (d >= a.d_end || dn >= n_disp) break;
         if (interior)
-            fast_disparity_pass<RG, WORD64, TH, QOUT, true>(a, t, d, lane, x, ty0, x_in, x_valid, invAX1, invAX2, lane1,
+            fast_disparity_pass<RG, WORD64, TH, QOUT, true>(a, t, d, lane, x, ty0, x_in, x_valid, invAX1, cxf, lane1,
                                                             inv_scale_d);
         else
-            fast_disparity_pass<RG, WORD64, TH, QOUT, false>(a, t, d, lane, x, ty0, x_in, x_valid, invAX1, invAX2, lane1,
+            fast_disparity_pass<RG, WORD64, TH, QOUT, false>(a, t, d, lane, x, ty0, x_in, x_valid, invAX1, cxf, lane1,
                                                              inv_scale_d);
     }
     __syncthreads();
@@ -324,9 +368,11 @@ template <> struct FastTile<1, true> { static constexpr int TH = 62; };
 template <> struct FastTile<2, true> { static constexpr int TH = 62; };
 template <> struct FastTile<3, true> { static constexpr int TH = 58; };
 template <> struct FastTile<4, true> { static constexpr int TH = 56; };
-constexpr int FF_NW = 16;
+#ifndef FF_NW
+#define FF_NW 16
+#endif
 
-template <int RG, bool WORD64, bool QOUT>
+template <int RG, bool WORD64, bool QOUT, int NWV = FF_NW>
 static int launch_fast_q(const FastArgs &a, hipStream_t s) {
     constexpr int TH = FastTile<RG, WORD64>::TH;
     constexpr int NI = TH + 4 * RG, NJ = TH + 2 * RG, TWV = 64 - 4 * RG;
@@ -336,16 +382,24 @@ static int launch_fast_q(const FastArgs &a, hipStream_t s) {
                             sizeof(float) * NJ * 64 + sizeof(float) * NI * 64 + sizeof(float) * (TH * 64 + 16) + 16 +
                             sizeof(short) * NI * 64;
     static_assert(smem <= 160 * 1024, "tile image exceeds the LDS");
-    auto kern = fused_guided_fast_kernel<RG, WORD64, TH, FF_NW, QOUT>;
+    auto kern = fused_guided_fast_kernel<RG, WORD64, TH, NWV, QOUT>;
     SHP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
     dim3 grid(ceil_div(a.W, TWV), ceil_div(a.H, TH), a.n_slices);
-    hipLaunchKernelGGL(kern, grid, dim3(FF_NW * 64), smem, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, s, a);
     SHP_LAUNCH_CHECK();
     return STEREO_OK;
 }
 template <int RG, bool WORD64>
 static int launch_fast_t(const FastArgs &a, hipStream_t s) {
+#ifdef FF_EXPERIMENT_NW
+    if (RG == 3 && !WORD64 && !a.q_out) {
+        const char *e = getenv("STEREO_FAST_NW");
+        int nw = e ? atoi(e) : 16;
+        if (nw == 8) return launch_fast_q<3, false, false, 8>(a, s);
+        if (nw == 12) return launch_fast_q<3, false, false, 12>(a, s);
+    }
+#endif
     return a.q_out ? launch_fast_q<RG, WORD64, true>(a, s) : launch_fast_q<RG, WORD64, false>(a, s);
 }
 
