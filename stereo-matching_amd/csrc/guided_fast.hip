@@ -91,7 +91,7 @@ struct TileLds {
     float *inv;      // [NJ][64] 1 / ((var + eps) * window area)
     float *glo;      // [NI][64] guide - k * 2^-s
     float *gout;     // [TH][64] (+pad) guide at the output pixels
-    int *next_d;
+    int *next_d;     // [0] next disparity to hand out, [1] lowest disparity whose costs are all `large`
     short *k;        // [NI][64] round(guide * 2^s)
 };
 
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
         t.cy2[o] = (y < H) ? (float)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.f;
     }
     if (threadIdx.x <= WIN) t.invtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
-    if (threadIdx.x == 0) *t.next_d = 0;
+    if (threadIdx.x == 0) { t.next_d[0] = 0; t.next_d[1] = 0x7fffffff; }
     __syncthreads();
 
     const int x = tx0 - HALO + lane;   // column of this lane's cost and of its final output
@@ -337,6 +337,13 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
         dn = __builtin_amdgcn_readfirstlane(dn);
         const int d = a.d_begin + dn * a.n_slices + (int)blockIdx.z;
         if (d >= a.d_end || dn >= n_disp) break;
+        // Every column this wavefront reads lies left of the first valid match (x - d < radius):
+        // all costs are `large`, and a constant window filters to exactly that constant.  Only
+        // the lowest such disparity can win a tie, so remember it and skip the pass.
+        if (!QOUT && tx0 - HALO + 63 - d < R) {
+            if (lane == 0) atomicMin(&t.next_d[1], d);
+            continue;
+        }
         if (interior)
             fast_disparity_pass<RG, WORD64, TH, QOUT, true>(a, t, d, lane, x, ty0, x_in, x_valid, invAX1, cxf, lane1,
                                                             inv_scale_d);
@@ -345,11 +352,17 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
                                                              inv_scale_d);
     }
     __syncthreads();
+    const int skipped_d = t.next_d[1];
+    const float large_f = (float)a.large_units * a.unit;
     for (int idx = threadIdx.x; idx < TH * 64; idx += NW * 64) {
         int o = idx >> 6, l = idx & 63;
         int gy = ty0 + o, gx = tx0 - HALO + l;
         if (l >= HALO && l < 64 - HALO && gy < H && gx < W) {
             uint64_t key = t.key[idx];
+            if (skipped_d != 0x7fffffff) {
+                const uint64_t kl = make_key(large_f, (uint32_t)skipped_d);
+                key = kl < key ? kl : key;
+            }
             if (a.atomic_out) atomicMin(reinterpret_cast<unsigned long long *>(&a.keys[(size_t)gy * W + gx]),
                                         (unsigned long long)key);
             else a.keys[(size_t)gy * W + gx] = key;
