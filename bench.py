@@ -79,6 +79,7 @@ def main() -> None:
     import torch.distributed as dist
 
     import _native
+    import sharding
     from synth import synth_pair_gray
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,17 +109,15 @@ def main() -> None:
     _native.check(lib.stereo_fused_workspace_bytes(H, W, params, ctypes.byref(ws_bytes)))
     workspace = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
     n = H * W
-    chunk = (n + world - 1) // world
+    chunk = sharding.padded_chunk(n, world)
     n_pad = chunk * world
     keys = torch.empty(n_pad, dtype=torch.int64, device=dev)
     keys.fill_(-(1 << 63) + 0)  # never read: the pad only travels through the exchange
-    d_begin, d_end = rank * D // world, (rank + 1) * D // world
+    d_begin, d_end = sharding.shard_range(D, world, rank)
     if world > 1:
         recv = torch.empty(n_pad, dtype=torch.int64, device=dev)
         disp_part = torch.empty(chunk, dtype=torch.int32, device=dev)
         cost_part = torch.empty(chunk, dtype=torch.float32, device=dev)
-        disp_all = [torch.empty(chunk, dtype=torch.int32, device=dev) for _ in range(world)] if rank == 0 else None
-        cost_all = [torch.empty(chunk, dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
     else:
         disp = torch.empty(n, dtype=torch.int32, device=dev)
         cost = torch.empty(n, dtype=torch.float32, device=dev)
@@ -133,12 +132,13 @@ def main() -> None:
             return
         # every rank sends pixel slice j of its shard's keys to rank j over its direct xGMI link,
         # min-merges the N slices it receives, unpacks them and hands its slice to rank 0
-        dist.all_to_all_single(recv, keys)
-        for j in range(1, world):
-            _native.check(lib.stereo_merge_keys_dev(recv.data_ptr(), recv.data_ptr() + j * chunk * 8, chunk, stream))
-        _native.check(lib.stereo_unpack_keys_dev(recv.data_ptr(), chunk, disp_part.data_ptr(), cost_part.data_ptr(), stream))
-        dist.gather(disp_part, disp_all, dst=0)
-        dist.gather(cost_part, cost_all, dst=0)
+        def merge(dst, src):
+            _native.check(lib.stereo_merge_keys_dev(dst.data_ptr(), src.data_ptr(), dst.numel(), stream))
+
+        merged = sharding.exchange_and_merge(keys, world, merge, recv=recv)
+        _native.check(lib.stereo_unpack_keys_dev(merged.data_ptr(), chunk, disp_part.data_ptr(), cost_part.data_ptr(), stream))
+        sharding.gather_slices(disp_part, world, rank)
+        sharding.gather_slices(cost_part, world, rank)
 
     def fence() -> None:
         if world > 1:

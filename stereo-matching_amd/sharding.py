@@ -1,0 +1,107 @@
+"""Multi-GPU execution of the stereo hot path on one node (one process per GPU, RCCL over xGMI).
+
+Two partitionings, both taken from how the reference's work decomposes:
+
+* Disparity-range sharding of ONE frame.  Every disparity layer is filtered independently
+  (reference stereo.py:145-166) and WTA is a lexicographic min over (cost, d)
+  (stereo.py:167-170), so rank r searches d in [r*D/N, (r+1)*D/N) on replicated images and the
+  per-pixel results are merged.  Results travel as packed 64-bit keys
+  (ordered float32 cost << 32 | d): an UNSIGNED min of keys is exactly the reference's rule
+  "lowest cost, ties to the lowest disparity", so the merged frame is bit-identical to the
+  unsharded one for any partition.
+  The exchange is an all-to-all: rank r sends pixel slice j of its keys straight to rank j (one
+  hop on the point-to-point xGMI mesh, all links busy at once), min-merges the N slices it
+  receives, unpacks its slice and hands it to rank 0.  Ring all-reduce would move the same bytes
+  over one link at a time.
+
+* Scene-parallel batches (reference stereo.py:722-778 loops scenes sequentially): scenes are
+  dealt to ranks longest-first by H*W*ndisp; no collective on the data path, only a gather of
+  the per-scene metric dicts.
+
+The functions take the collective backend from the initialised torch.distributed process group
+(`nccl` on GPUs; the CPU rehearsal tests run the same code over `gloo`).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+
+def shard_range(dmax: int, world: int, rank: int) -> Tuple[int, int]:
+    """Disparities [d_begin, d_end) of `rank`: contiguous, near-equal, covering [0, dmax)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    return rank * dmax // world, (rank + 1) * dmax // world
+
+
+def padded_chunk(n_pixels: int, world: int) -> int:
+    """Pixels per rank after padding the frame to a multiple of `world`."""
+    return (n_pixels + world - 1) // world
+
+
+def exchange_and_merge(keys, world: int, merge_fn: Callable, recv=None):
+    """All-to-all the key slices and min-merge them.
+
+    keys : int64 tensor [world * chunk] holding the uint64 key bits of THIS rank's shard
+    merge_fn(dst, src) : in-place unsigned 64-bit min of two [chunk] tensors
+    Returns the [chunk] tensor of merged keys for this rank's pixel slice.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if keys.numel() % world:
+        raise ValueError("keys must be padded to a multiple of the world size")
+    chunk = keys.numel() // world
+    if world == 1:
+        return keys[:chunk]
+    if recv is None:
+        recv = torch.empty_like(keys)
+    dist.all_to_all_single(recv, keys)
+    merged = recv[:chunk]
+    for j in range(1, world):
+        merge_fn(merged, recv[j * chunk:(j + 1) * chunk])
+    return merged
+
+
+def gather_slices(part, world: int, rank: int, dst: int = 0):
+    """Gather equal-length slices on `dst`; returns the concatenated tensor there, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return part
+    bufs = [torch.empty_like(part) for _ in range(world)] if rank == dst else None
+    dist.gather(part, bufs, dst=dst)
+    return torch.cat(bufs) if rank == dst else None
+
+
+def deal_scenes(sizes: Sequence[int], world: int) -> List[List[int]]:
+    """Longest-first greedy assignment of scene indices to ranks (balanced total work)."""
+    if world <= 0:
+        raise ValueError("world must be positive")
+    order = sorted(range(len(sizes)), key=lambda i: (-sizes[i], i))
+    load = [0] * world
+    plan: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        plan[r].append(i)
+        load[r] += sizes[i]
+    return plan
+
+
+def run_scenes_parallel(scene_names: Sequence[str], sizes: Sequence[int], world: int, rank: int,
+                        run_scene: Callable[[str], Dict[str, float]]) -> Optional[Dict[str, Dict[str, float]]]:
+    """Run this rank's share of the scenes and gather {scene: metrics} on rank 0."""
+    import torch.distributed as dist
+
+    plan = deal_scenes(sizes, world)
+    mine = {scene_names[i]: run_scene(scene_names[i]) for i in plan[rank]}
+    if world == 1:
+        return mine
+    gathered: Optional[list] = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0)
+    if rank != 0:
+        return None
+    out: Dict[str, Dict[str, float]] = {}
+    for part in gathered:
+        out.update(part)
+    return {k: out[k] for k in sorted(out)}
