@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__
             unsigned int o = __shfl_down(b, off, 64);
             b = o > b ? o : b;
         }
-        if ((threadIdx.x & 63) == 0 && b) atomicMax(gmax_bits, b);
+        // read first: almost every wavefront sees a value already at least as large
+        if ((threadIdx.x & 63) == 0 && b > *static_cast<volatile unsigned int *>(gmax_bits)) atomicMax(gmax_bits, b);
     }
 }
 

@@ -424,7 +424,9 @@ bool fused_fast_supported(const CensusCfg &cfg, int guided_radius) {
 int fused_fast_slices(int H, int W, int guided_radius, int n_disp) {
     int tiles = ceil_div(W, 64 - 4 * guided_radius) * ceil_div(H, 65);
     int s = 1;
-    while (tiles * s < 2048 && s * FF_NW * 4 <= n_disp) s *= 2;
+    const char *e = getenv("STEREO_FAST_SLICES");
+    if (e) return atoi(e) > 0 ? atoi(e) : 1;
+    while (tiles * s < 1024 && s * FF_NW * 4 <= n_disp) s *= 2;
     return s;
 }
 
