@@ -34,6 +34,7 @@ extern "C" {
 #define STEREO_DT_F32 0
 #define STEREO_DT_F64 1
 #define STEREO_DT_U8 2
+#define STEREO_DT_U16 3 /* image files only (to_gray) */
 
 /* aggregation filter (stereo.py:136-165) */
 #define STEREO_FILTER_GUIDED 0
@@ -111,6 +112,19 @@ int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dty
 int stereo_compute_disparity_host(const void *left, const void *right, int dtype, int height, int width,
                                   int dmax, const StereoParams *params, int d_begin, int d_end,
                                   int32_t *out_disparity, float *out_min_cost);
+
+/* ---- stereo_io.py / metrics: the steps either side of the path ------------------------------ */
+/* to_gray (stereo_io.py:47-75): image[H][W][channels] (channels 1 or >= 3, the first three are R, G, B; uint8, uint16 or
+ * float32) -> float32 gray[H][W]; normalize != 0 divides by float32(scale) and clips to [0, 1]. */
+int stereo_to_gray_host(const void *image, int dtype, int height, int width, int channels, int normalize,
+                        double scale, float *out_gray);
+/* nanmin / nanmax of a float32 buffer (_resolve_normalization_scale, stereo_io.py:38-39).
+ * Returns +inf / -inf when every element is NaN or n == 0. */
+int stereo_nan_minmax_host(const float *values, size_t n, float *out_min, float *out_max);
+/* _compute_pbm_rms (stereo.py:532-577): over pixels with finite ground truth and mask != 0.
+ * out[0] = pbm (percent), out[1] = rms, out[2] = valid pixel count. EINVAL when no pixel is valid. */
+int stereo_pbm_rms_host(const int32_t *disparity, const float *ground_truth, const uint8_t *mask, int height,
+                        int width, double bad_threshold, double *out);
 
 /* ---- device-pointer path (bench, multi-GPU sharding) ------------------------------------ */
 /* Scratch the fused path needs for one (H, W) frame, in bytes. */

@@ -206,3 +206,45 @@ def compute_disparity(left: np.ndarray, right: np.ndarray, dmax: int, wct_radius
                                      ctypes.c_int(threads))
     _check(rc, "compute_disparity")
     return disp, cost
+
+
+# ---- steps either side of the hot path (numpy restatements; test infrastructure only) ----------
+def to_gray(image: np.ndarray, normalize: bool = False, max_value=None) -> np.ndarray:
+    """Reference stereo_io.py:47-75 with stereo_io.py:22-44 for the scale: float32 products and
+    sums in source order, division by float32(scale), clip to [0, 1]."""
+    image = np.asarray(image)
+    if image.ndim == 2:
+        gray = image.astype(np.float32)
+    elif image.ndim == 3 and image.shape[2] >= 3:
+        rgb = image[..., :3].astype(np.float32)
+        gray = (np.float32(0.299) * rgb[..., 0] + np.float32(0.587) * rgb[..., 1]) + np.float32(0.114) * rgb[..., 2]
+    else:
+        raise ValueError("unsupported image shape")
+    gray = gray.astype(np.float32)
+    if not normalize:
+        return gray
+    if max_value is not None:
+        if max_value <= 0:
+            raise ValueError("max_value must be positive")
+        scale = float(max_value)
+    elif np.issubdtype(image.dtype, np.integer):
+        scale = float(np.iinfo(image.dtype).max)
+    else:
+        lo, hi = float(np.nanmin(image)), float(np.nanmax(image))
+        if lo >= 0.0 and hi <= 1.0:
+            scale = 1.0
+        elif hi <= 0.0:
+            raise ValueError("the image maximum must be positive")
+        else:
+            scale = hi
+    return np.clip(gray / np.float32(scale), 0.0, 1.0).astype(np.float32)
+
+
+def pbm_rms(disparity: np.ndarray, ground_truth: np.ndarray, valid_mask: np.ndarray, bad_threshold: float):
+    """Reference stereo.py:560-577: (pbm percent, rms, valid pixel count)."""
+    ok = np.isfinite(ground_truth) & valid_mask
+    n = int(np.sum(ok))
+    if n == 0:
+        raise ValueError("no valid pixel")
+    diff = np.abs(disparity.astype(np.float32) - ground_truth.astype(np.float32))[ok]
+    return float(np.mean(diff > bad_threshold) * 100.0), float(np.sqrt(np.mean(diff ** 2))), n

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstereo_hip.so")
 
 OK, EINVAL, EUNSUPPORTED, EHIP, ENOMEM, ENONFINITE = 0, -1, -2, -3, -4, -5
-DT_F32, DT_F64, DT_U8 = 0, 1, 2
+DT_F32, DT_F64, DT_U8, DT_U16 = 0, 1, 2, 3
 FILTER_GUIDED, FILTER_MEDIAN, FILTER_MEDIAN_U8Q, FILTER_GAUSSIAN, FILTER_BILATERAL = 0, 1, 2, 3, 4
 
 
@@ -62,6 +62,9 @@ _SIGNATURES = {
     "stereo_keys_to_i64_dev": [_VP, _VP, _SZ, _VP],
     "stereo_keys_from_i64_dev": [_VP, _VP, _SZ, _VP],
     "stereo_unpack_keys_dev": [_VP, _SZ, _VP, _VP, _VP],
+    "stereo_to_gray_host": [_VP, _I, _I, _I, _I, _I, _D, _VP],
+    "stereo_nan_minmax_host": [_VP, _SZ, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)],
+    "stereo_pbm_rms_host": [_VP, _VP, _VP, _I, _I, _D, _VP],
     "stereo_debug_force_general_kernel": [_I],
     "stereo_profile_begin": [_I],
     "stereo_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],

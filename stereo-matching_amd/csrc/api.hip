@@ -591,4 +591,56 @@ int stereo_bilateral_filter_host(const float *image, int H, int W, double sigma,
     return gauss_like_host(image, H, W, sigma, out, true);
 }
 
+int stereo_to_gray_host(const void *image, int dtype, int H, int W, int channels, int normalize, double scale,
+                        float *out_gray) {
+    if (H < 0 || W < 0) { set_error("negative image size"); return STEREO_EINVAL; }
+    if (channels != 1 && channels < 3) { set_error("unsupported image shape"); return STEREO_EINVAL; }
+    if (normalize && !(scale > 0)) { set_error("max_value must be positive"); return STEREO_EINVAL; }
+    size_t esz = dtype == STEREO_DT_U8 ? 1 : dtype == STEREO_DT_U16 ? 2 : dtype == STEREO_DT_F32 ? 4 : 0;
+    if (!esz) { set_error("to_gray takes uint8, uint16 or float32 pixels"); return STEREO_EINVAL; }
+    size_t npix = (size_t)H * W;
+    if (npix == 0) return STEREO_OK;
+    DevBuf di, dout;
+    SHP_TRY(di.alloc(npix * channels * esz)); SHP_TRY(dout.alloc(npix * 4));
+    SHP_HIP(hipMemcpy(di.p, image, npix * channels * esz, hipMemcpyHostToDevice));
+    SHP_TRY(launch_to_gray(di.p, dtype, npix, channels, normalize, (float)scale, dout.as<float>(), nullptr));
+    SHP_HIP(hipMemcpy(out_gray, dout.p, npix * 4, hipMemcpyDeviceToHost));
+    return STEREO_OK;
+}
+
+int stereo_nan_minmax_host(const float *values, size_t n, float *out_min, float *out_max) {
+    DevBuf dv, mm;
+    SHP_TRY(dv.alloc(n * 4)); SHP_TRY(mm.alloc(8));
+    if (n) SHP_HIP(hipMemcpy(dv.p, values, n * 4, hipMemcpyHostToDevice));
+    SHP_TRY(launch_nan_minmax(dv.as<float>(), n, mm.as<uint32_t>(), nullptr));
+    uint32_t h[2];
+    SHP_HIP(hipMemcpy(h, mm.p, 8, hipMemcpyDeviceToHost));
+    *out_min = h[0] == 0xffffffffu && h[1] == 0u ? INFINITY : ordered_to_f32(h[0]);
+    *out_max = h[0] == 0xffffffffu && h[1] == 0u ? -INFINITY : ordered_to_f32(h[1]);
+    return STEREO_OK;
+}
+
+int stereo_pbm_rms_host(const int32_t *disparity, const float *ground_truth, const uint8_t *mask, int H, int W,
+                        double bad_threshold, double *out) {
+    SHP_TRY(check_image_dims(H, W));
+    if (!(bad_threshold > 0)) { set_error("bad_threshold must be positive"); return STEREO_EINVAL; }
+    size_t n = (size_t)H * W;
+    DevBuf dd, dg, dm, acc, sq;
+    SHP_TRY(dd.alloc(n * 4)); SHP_TRY(dg.alloc(n * 4)); SHP_TRY(dm.alloc(n)); SHP_TRY(acc.alloc(16)); SHP_TRY(sq.alloc(8));
+    SHP_HIP(hipMemcpy(dd.p, disparity, n * 4, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dg.p, ground_truth, n * 4, hipMemcpyHostToDevice));
+    SHP_HIP(hipMemcpy(dm.p, mask, n, hipMemcpyHostToDevice));
+    SHP_TRY(launch_metrics(dd.as<int32_t>(), dg.as<float>(), dm.as<uint8_t>(), n, (float)bad_threshold,
+                           acc.as<unsigned long long>(), sq.as<double>(), nullptr));
+    unsigned long long h[2];
+    double hs = 0.0;
+    SHP_HIP(hipMemcpy(h, acc.p, 16, hipMemcpyDeviceToHost));
+    SHP_HIP(hipMemcpy(&hs, sq.p, 8, hipMemcpyDeviceToHost));
+    if (h[0] == 0) { set_error("ground truth has no valid pixel"); return STEREO_EINVAL; }
+    out[0] = (double)h[1] / (double)h[0] * 100.0;
+    out[1] = std::sqrt(hs / (double)h[0]);
+    out[2] = (double)h[0];
+    return STEREO_OK;
+}
+
 }  // extern "C"

@@ -164,4 +164,12 @@ int launch_median_u8q(const float *d_img, int H, int W, int r, uint32_t *d_mm, u
 int launch_dsi_to_layers(const float *d_dsi, size_t npix, int D, float *d_layers, hipStream_t s);
 int launch_wta_update(const float *d_layer, size_t n, int d, uint64_t *d_keys, hipStream_t s);
 
+
+// gray conversion and metrics (io_ops.hip)
+int launch_to_gray(const void *d_img, int dtype, size_t npix, int channels, int normalize, float scale, float *d_out,
+                   hipStream_t s);
+int launch_nan_minmax(const float *d_v, size_t n, uint32_t *d_mm, hipStream_t s);
+int launch_metrics(const int32_t *d_disp, const float *d_gt, const uint8_t *d_mask, size_t n, float threshold,
+                   unsigned long long *d_acc, double *d_acc_sq, hipStream_t s);
+
 }  // namespace shp

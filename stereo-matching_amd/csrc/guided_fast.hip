@@ -121,7 +121,6 @@ __device__ __forceinline__ void fast_disparity_pass(
     int kr[WIN];
     float gr[WIN];
     double ar[WIN], br[WIN];
-    WordT rwd[WIN];
 #pragma unroll
     for (int k = 0; k < WIN; ++k) { pr[k] = 0u; kr[k] = 0; gr[k] = 0.f; ar[k] = 0.0; br[k] = 0.0; }
     const bool xd_valid = x_valid && (x - d >= R);
@@ -132,8 +131,6 @@ __device__ __forceinline__ void fast_disparity_pass(
         int y = ty0 - HALO + i;
         return INTERIOR ? y : min(max(y, 0), H - 1);
     };
-#pragma unroll
-    for (int k = 0; k < WIN; ++k) rwd[k] = rp[(size_t)row_of(k) * W];
 
     const double ia_interior = invAX1 * (1.0 / (double)WIN);
     const float area_interior = cxf * (float)WIN;
@@ -153,11 +150,32 @@ __device__ __forceinline__ void fast_disparity_pass(
         LDS_AS uint64_t *keyg = lds_lane_ptr(t.key + (base - 2 * HALO) * 64 + lane);
         LDS_AS const double *iay1g = lds_lane_ptr(t.iay1 + (base - HALO));
         LDS_AS const float *cy2g = lds_lane_ptr(t.cy2 + (base - 2 * HALO));
+        // The operands a row needs first (census words, guide split) are fetched one row ahead;
+        // the ones it needs late (guide mean, 1/den, guide of the output row) at the start of the
+        // row itself, so that every LDS / L2 latency overlaps arithmetic.
+        struct RowHead {
+            WordT L, R; int k; float glo;
+        };
+        auto fetch_head = [&](int k) {
+            RowHead r;
+            r.L = Lg[k * 64];
+            r.k = (int)kg[k * 64];
+            r.glo = glog[k * 64];
+            r.R = rp[(size_t)row_of(min(base + k, NI - 1)) * W];
+            return r;
+        };
+        RowHead cur = fetch_head(0);
 #pragma unroll
         for (int k = 0; k < WIN; ++k) {
             const int i = base + k;
+            const RowHead nxt = fetch_head(k + 1);
+            const double mG = mGg[k * 64];
+            const float inv_f = invg[k * 64];
+            float g[WIN];
+#pragma unroll
+            for (int u = 0; u < WIN; ++u) g[u] = goutg[k * 64 + u];
             // 1. cost in units; k*p and g_lo*p
-            const uint32_t fs = field_sum((WordT)(Lg[k * 64] ^ rwd[k]));
+            const uint32_t fs = field_sum((WordT)(cur.L ^ cur.R));
             uint32_t p;
             if (INTERIOR) {
                 p = xd_valid ? fs : large_lane;
@@ -167,11 +185,8 @@ __device__ __forceinline__ void fast_disparity_pass(
                 p = (rowv && xd_valid) ? fs : large_lane;
                 p = rowi ? p : 0u;
             }
-            rwd[k] = rp[(size_t)row_of(min(i + WIN, NI - 1)) * W];  // same ring slot, next group
-            const int kk = (int)kg[k * 64];
-            const float glo = glog[k * 64];
-            const int kp = __mul24(kk, (int)p);
-            const float gl = glo * (float)p;
+            const int kp = __mul24(cur.k, (int)p);
+            const float gl = cur.glo * (float)p;
             // 2. vertical running sums over rows [i - 2r, i]
             C1 += p - pr[k];
             I2 += kp - kr[k];
@@ -192,9 +207,8 @@ __device__ __forceinline__ void fast_disparity_pass(
                 //    a = (sum(G p) - mG * sum(p)) / (area * den),  b = sum(p) / area - a * mG
                 const double ia = INTERIOR ? ia_interior : iay1g[k] * invAX1;
                 const double s1d = (double)s1;
-                const double mG = mGg[k * 64];
                 const double u = fma(-mG, s1d, fma((double)si, inv_scale_d, (double)sf));
-                const double av = u * (double)invg[k * 64];
+                const double av = u * (double)inv_f;
                 const double bv = fma(-av, mG, s1d * ia);
                 // 5. vertical running sums over stage-1 rows [j - 2r, j]
                 const int k2 = (k + 1) % WIN;
@@ -205,16 +219,15 @@ __device__ __forceinline__ void fast_disparity_pass(
                 if (STEADY || i >= 2 * HALO) {
                     // 6. sums over lanes [l, l + 2r] (stage-1 columns x - r .. x + r)
                     const int o = i - 2 * HALO;
-                    LDS_AS const float *grow = goutg + k * 64;
-                    const float gx = grow[0];
+                    const float gx = g[0];
                     const float ef = (float)fma(A, (double)gx, B);  // column's own-guide output (7 rows)
                     float ash = (float)A;
                     float se = ef, dsum = 0.f;
 #pragma unroll
-                    for (int u = 1; u <= 2 * RG; ++u) {
+                    for (int u2 = 1; u2 <= 2 * RG; ++u2) {
                         se = ef + dpp_f<DPP_WAVE_SHL1>(se);
                         ash = dpp_mov_f<DPP_WAVE_SHL1>(ash);          // A of column x + u
-                        dsum = fmaf(ash, gx - grow[u], dsum);         // A_j * (G(x) - G_j)
+                        dsum = fmaf(ash, gx - g[u2], dsum);           // A_j * (G(x) - G_j)
                     }
                     // 7. q and the running WTA (NaN never wins: it is replaced by +inf)
                     //    t32 / area by one Newton step on the reciprocal: exact whenever the quotient is
@@ -234,6 +247,7 @@ __device__ __forceinline__ void fast_disparity_pass(
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
+            cur = nxt;
         }
     };
     static_assert(2 * WIN >= 2 * HALO, "two peeled groups cover the start-up rows");
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char *sp = smem_raw;
     TileLds<WordT> t;
-    t.mG = reinterpret_cast<double *>(sp); sp += sizeof(double) * NJ * 64;
+    t.mG = reinterpret_cast<double *>(sp); sp += sizeof(double) * NJ * 64;  // (read-ahead past the last row lands in the next array)
     t.key = reinterpret_cast<uint64_t *>(sp); sp += sizeof(uint64_t) * TH * 64;
     t.iay1 = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((NJ + 1) / 2 * 2);
     t.cy2 = reinterpret_cast<float *>(sp); sp += sizeof(double) * ((TH + 1) / 2 * 2);

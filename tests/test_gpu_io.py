@@ -1,0 +1,170 @@
+"""GPU parity of the steps either side of the hot path (gray conversion, metrics) and the
+command line end to end on a small synthetic Middlebury-style dataset."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return load_golden("io_metrics")
+
+
+def test_to_gray_bit_exact_vs_reference(gold):
+    import stereo_io
+
+    names = [k[len("gray_in_"):] for k in gold if k.startswith("gray_in_")]
+    assert len(names) == 9
+    for name in names:
+        img = gold[f"gray_in_{name}"]
+        raw = stereo_io.to_gray(img)
+        norm = stereo_io.to_gray(img, normalize=True)
+        assert raw.dtype == np.float32 and norm.dtype == np.float32
+        np.testing.assert_array_equal(raw, gold[f"gray_raw_{name}"], err_msg=name)
+        np.testing.assert_array_equal(norm, gold[f"gray_norm_{name}"], err_msg=name)
+    np.testing.assert_array_equal(stereo_io.to_gray(gold["gray_in_rgb_u8"], True, 200.0), gold["gray_norm_rgb_u8_max200"])
+
+
+def test_to_gray_full_frame_vs_oracle(oracle):
+    import stereo_io
+
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(1000, 1482, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(stereo_io.to_gray(img, normalize=True), oracle.to_gray(img, normalize=True))
+    sl = img[::2, 1::3]  # non-contiguous view
+    np.testing.assert_array_equal(stereo_io.to_gray(sl), oracle.to_gray(sl))
+
+
+def test_normalization_scale_of_float_images():
+    import stereo_io
+
+    a = np.array([[0.25, np.nan], [0.5, 1.0]], np.float32)
+    assert stereo_io._resolve_normalization_scale(a, None) == 1.0
+    assert stereo_io._resolve_normalization_scale(a * 300.0, None) == 300.0
+    assert stereo_io._resolve_normalization_scale(np.array([[-0.5, 0.75]], np.float32), None) == 0.75
+    with pytest.raises(ValueError):
+        stereo_io._resolve_normalization_scale(np.array([[-3.0, -1.0]], np.float32), None)
+
+
+def test_metrics_vs_reference(gold):
+    import stereo
+
+    for thr in (0.5, 1.0, 2.0):
+        m = stereo._compute_pbm_rms(gold["metrics_disp"], gold["metrics_gt"], gold["metrics_mask"], thr)
+        want = gold[f"metrics_thr{thr}"]
+        assert set(m) == {"pbm", "rms", "bad_threshold", "valid_pixel_count"}
+        assert m["pbm"] == want[0]  # exact: a ratio of two integer counts
+        assert abs(m["rms"] - want[1]) <= 1e-6 * want[1]  # the reference sums float32 squares pairwise in float32
+        assert m["bad_threshold"] == want[2] and m["valid_pixel_count"] == want[3]
+    with pytest.raises(ValueError):
+        stereo._compute_pbm_rms(gold["metrics_disp"], gold["metrics_gt"], np.zeros_like(gold["metrics_mask"]), 1.0)
+
+
+def _write_scene(folder, h, w, dmax, seed):
+    """im0/im1 PNGs (RGB), disp0.pfm ground truth and disp0-n.pgm mask of one synthetic scene."""
+    from PIL import Image
+
+    import stereo_io
+    from synth import synth_pair_u8
+
+    left, right, d_row = synth_pair_u8(h, w, dmax, seed)
+    os.makedirs(folder)
+    for name, g in (("im0.png", left), ("im1.png", right)):
+        rgb = np.stack([g, np.roll(g, 1, axis=1), g[::-1]], axis=-1)
+        Image.fromarray(rgb).save(os.path.join(folder, name))
+    truth = np.repeat(np.asarray(d_row, np.float32)[:, None], w, axis=1)
+    truth[:, :3] = np.inf
+    stereo_io.write_pfm(os.path.join(folder, "disp0.pfm"), truth)
+    mask = np.full((h, w), 255, np.uint8)
+    mask[:5] = 0
+    Image.fromarray(mask).save(os.path.join(folder, "disp0-n.pgm"))
+
+
+def _expected_scene(oracle, folder, dmax, filter_kind=0, eps=0.01):
+    import stereo_io
+
+    lg = oracle.to_gray(stereo_io.read_image(os.path.join(folder, "im0.png")), normalize=True)
+    rg = oracle.to_gray(stereo_io.read_image(os.path.join(folder, "im1.png")), normalize=True)
+    disp, cost = oracle.compute_disparity(lg, rg, dmax, wct_radius=4, radius=3, eps_or_sigma=eps)
+    gt = stereo_io.read_pfm(os.path.join(folder, "disp0.pfm"))
+    mask = stereo_io.read_pgm_mask(os.path.join(folder, "disp0-n.pgm"))
+    return disp, cost, gt, mask
+
+
+def test_cli_single_scene_and_batch(oracle, tmp_path, capsys):
+    import stereo
+    import stereo_io
+
+    root = tmp_path / "dataset"
+    scenes = {"Alpha-perfect": (56, 96, 24, 11), "Beta-perfect": (48, 80, 16, 12)}
+    for name, (h, w, dmax, seed) in scenes.items():
+        _write_scene(str(root / name), h, w, dmax, seed)
+    os.makedirs(root / "Gamma-perfect")  # a folder the csv does not list is ignored
+    (root / "ndisp_summary.csv").write_text(
+        "scene,ndisp\nAlpha-perfect,24\nBeta-perfect,16\nAlpha-imperfect,24\nMissing-perfect,32\n", encoding="utf-8")
+    result = tmp_path / "result"
+
+    # --dataset <scene>
+    stereo.main(["--dataset", "Alpha-perfect"], dataset_root=str(root), result_root=str(result))
+    runs = sorted(os.listdir(result))
+    assert len(runs) == 1
+    run = result / runs[0]
+    assert sorted(os.listdir(run)) == ["disparity.npz", "disparity.png", "disparity_color.png", "metrics.json", "params.json"]
+    disp, cost = stereo_io.load_disparity_npz(str(run / "disparity.npz"))
+    want_d, want_c, gt, mask = _expected_scene(oracle, str(root / "Alpha-perfect"), 24)
+    assert disp.dtype == np.int32 and cost.dtype == np.float32
+    assert np.mean(disp == want_d) >= 0.999
+    same = disp == want_d
+    np.testing.assert_allclose(cost[same], want_c[same], rtol=1e-5)
+    metrics = json.loads((run / "metrics.json").read_text())
+    pbm, rms, n = oracle.pbm_rms(disp, gt, mask, 2.0)
+    assert metrics["pbm"] == pbm and abs(metrics["rms"] - rms) <= 1e-6 * rms and metrics["valid_pixel_count"] == float(n)
+    params = json.loads((run / "params.json").read_text())
+    assert params["dataset"] == "Alpha-perfect" and params["dmax"] == "24" and params["filter"] == "guided"
+    assert params["output_metrics_json"].endswith("metrics.json") and params["guided_eps"] == "0.01"
+    out = capsys.readouterr().out
+    assert "WCT cost volume: 24/24 (100.0%)" in out and "Guided Filter: 24/24 (100.0%)" in out and "PBM:" in out
+
+    # explicit paths, another filter, dmax override
+    a = root / "Beta-perfect"
+    stereo.main(["--left", str(a / "im0.png"), "--right", str(a / "im1.png"), "--gt", str(a / "disp0.pfm"),
+                 "--gt-mask", str(a / "disp0-n.pgm"), "--dmax", "12", "--filter", "gaussian", "--gaussian_sigma", "1.5"],
+                dataset_root=str(root), result_root=str(result))
+    run2 = [r for r in sorted(os.listdir(result)) if r != runs[0]]
+    assert len(run2) == 1
+    params = json.loads((result / run2[0] / "params.json").read_text())
+    assert params["filter"] == "gaussian" and params["gaussian_sigma"] == "1.5" and "guided_eps" not in params
+    assert params["dataset"] == "" and params["dmax"] == "12"
+    d2, _ = stereo_io.load_disparity_npz(str(result / run2[0] / "disparity.npz"))
+    assert d2.max() < 12
+
+    # --all-datasets
+    stereo.main(["--all-datasets", "--guided_eps", "0.0154"], dataset_root=str(root), result_root=str(result))
+    run3 = [r for r in sorted(os.listdir(result)) if r not in (runs[0], run2[0])]
+    assert len(run3) == 1
+    batch = result / run3[0]
+    assert sorted(os.listdir(batch)) == ["Alpha-perfect", "Beta-perfect", "metrics_summary.json"]
+    summary = json.loads((batch / "metrics_summary.json").read_text())
+    assert summary["scene_count"] == 2 and summary["bad_threshold"] == 2.0
+    assert list(summary["scenes"]) == ["Alpha-perfect", "Beta-perfect"]
+    assert summary["pbm_mean"] == float(np.mean([summary["scenes"][s]["pbm"] for s in summary["scenes"]]))
+    assert summary["rms_mean"] == float(np.mean([summary["scenes"][s]["rms"] for s in summary["scenes"]]))
+    for name, (h, w, dmax, seed) in scenes.items():
+        sub = batch / name
+        assert sorted(os.listdir(sub)) == ["disparity.npz", "disparity.png", "disparity_color.png", "params.json"]
+        d, c = stereo_io.load_disparity_npz(str(sub / "disparity.npz"))
+        want_d, want_c, gt, mask = _expected_scene(oracle, str(root / name), dmax, eps=0.0154)
+        assert np.mean(d == want_d) >= 0.999
+        pbm, rms, n = oracle.pbm_rms(d, gt, mask, 2.0)
+        assert summary["scenes"][name]["pbm"] == pbm
+        p = json.loads((sub / "params.json").read_text())
+        assert p["all_datasets"] == "True" and p["dataset"] == name and p["output_metrics_json"] == ""
+
+    with pytest.raises(ValueError):
+        stereo.main(["--dataset", "Alpha-perfect", "--all-datasets"], dataset_root=str(root), result_root=str(result))
