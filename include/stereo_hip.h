@@ -145,10 +145,11 @@ int stereo_keys_from_i64_dev(const int64_t *d_in, uint64_t *d_keys, size_t n, vo
 int stereo_unpack_keys_dev(const uint64_t *d_keys, size_t n, int32_t *d_disparity, float *d_min_cost,
                            void *stream);
 
-/* Test hook, no counterpart in the reference: when on, compute_disparity uses the general fused
- * kernel (float64 sums exchanged through LDS) even where the fast one applies, so the two can
- * be compared on the same input. */
-int stereo_debug_force_general_kernel(int on);
+/* Test hook, no counterpart in the reference: selects the fused guided kernel compute_disparity
+ * uses, so the variants can be compared on the same input.  0 = the best one that applies
+ * (default), 1 = the general kernel (float64 sums exchanged through LDS), 2 = the fast kernel
+ * with one image column per lane (the default fast kernel gives every lane two columns). */
+int stereo_debug_force_general_kernel(int mode);
 
 /* Timing of the dominant (fused) kernel with HIP events recorded on the launch stream, for
  * bench.py's roofline figure; no counterpart in the reference.  stereo_profile_begin creates up

@@ -11,9 +11,13 @@ pids=()
 for src in "${SRCS[@]}"; do
   obj="$HERE/csrc/obj/$(basename "${src%.hip}").o"
   OBJS+=("$obj")
-  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$HERE/csrc/common.hpp" -nt "$obj" || "$HERE/csrc/census_dev.hpp" -nt "$obj" || "$HERE/../include/stereo_hip.h" -nt "$obj" ]]; then
+  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$HERE/csrc/common.hpp" -nt "$obj" || "$HERE/csrc/census_dev.hpp" -nt "$obj" || "$HERE/csrc/fast_common.hpp" -nt "$obj" || "$HERE/../include/stereo_hip.h" -nt "$obj" ]]; then
+    # The fused kernels keep two independent columns per lane in scalar registers: packing them into
+    # v_pk_* instructions costs register shuffles and issues no faster on gfx950.
+    file_flags=""
+    case "$(basename "$src")" in guided_pair.hip|guided_fast.hip) file_flags="-fno-slp-vectorize" ;; esac
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$HERE/../include" -I"$HERE/csrc" \
-      -Wall -Wno-unused-function ${EXTRA_HIPCC_FLAGS:-} -c "$src" -o "$obj" &
+      -Wall -Wno-unused-function $file_flags ${EXTRA_HIPCC_FLAGS:-} -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done

@@ -30,7 +30,8 @@ struct ProfileState {
     bool enabled = false;
 };
 static ProfileState g_prof;
-static bool g_force_general = false;  // debugging/testing: route around the fast fused kernel
+// debugging/testing: 0 = best kernel, 1 = general fused kernel, 2 = fast kernel with one column per lane
+static int g_force_kernel = 0;
 
 static int check_params(const StereoParams *p) {
     if (!p) { set_error("params is NULL"); return STEREO_EINVAL; }
@@ -111,12 +112,16 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         SHP_TRY(launch_guide_stats(d_left, STEREO_DT_F32, H, W, p->guided_radius, p->guided_eps, mean, invden,
                                    gmax, s));
         if (d_begin == d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
-        const bool fast = fused_fast_supported(cfg, p->guided_radius) && !g_force_general;
-        const int slices = fast ? fused_fast_slices(H, W, p->guided_radius, d_end - d_begin) : 1;
-        if (fast && slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
+        const bool pair = fused_pair_supported(cfg, p->guided_radius) && g_force_kernel == 0;
+        const bool fast = fused_fast_supported(cfg, p->guided_radius) && g_force_kernel != 1;
+        const int slices = pair ? fused_pair_slices(H, W, p->guided_radius, d_end - d_begin)
+                           : fast ? fused_fast_slices(H, W, p->guided_radius, d_end - d_begin) : 1;
+        if (slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
         const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();
         if (prof) SHP_HIP(hipEventRecord(g_prof.start[g_prof.used], s));
-        int rc = fast ? launch_fused_guided_fast(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius,
+        int rc = pair ? launch_fused_guided_pair(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius,
+                                                 d_begin, d_end, slices, d_keys, d_q_out, s)
+                 : fast ? launch_fused_guided_fast(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius,
                                                  d_begin, d_end, slices, d_keys, d_q_out, s)
                       : launch_fused_guided(lw, rw, &cfg, nullptr, d_left, STEREO_DT_F32, mean, invden, H, W, dmax,
                                             p->guided_radius, d_begin, d_end, d_keys, d_q_out, 0, s);
@@ -294,7 +299,7 @@ int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int 
 }
 
 int stereo_debug_force_general_kernel(int on) {
-    g_force_general = on != 0;
+    g_force_kernel = on;
     return STEREO_OK;
 }
 

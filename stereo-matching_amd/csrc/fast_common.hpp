@@ -1,0 +1,61 @@
+// Pieces shared by the fast fused census-cost + guided-filter + WTA kernels
+// (guided_fast.hip: one column per lane, guided_pair.hip: two columns per lane).
+#pragma once
+
+#include "census_dev.hpp"
+
+namespace shp {
+
+struct FastArgs {
+    const void *lw;         // left census words
+    const void *rw;         // right census words
+    const float *guide;     // [H][W]
+    const double *mean;     // [H][W] box mean of the guide
+    const double *invden;   // [H][W] 1 / (var + eps32)
+    const float *gmax;      // max |guide| (device scalar)
+    uint64_t *keys;         // [H][W] packed (cost, d)
+    float *q_out;           // optional [D][H][W]
+    int H, W, D;
+    int d_begin, d_end;     // disparity range of the launch
+    int n_slices;           // gridDim.z; slice z handles every n_slices-th chunk of the range
+    int radius;             // census radius
+    float unit;             // value of one cost unit
+    uint32_t large_units;   // `large` in cost units
+    int atomic_out;
+};
+
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// LDS pointer whose value the optimiser cannot see through: accesses relative to it keep their
+// small row offsets as instruction immediates instead of re-adding the (> 64 KiB) array base.
+#define LDS_AS __attribute__((address_space(3)))
+template <typename T>
+__device__ __forceinline__ LDS_AS T *lds_lane_ptr(T *generic) {
+    unsigned addr = (unsigned)(size_t)(LDS_AS T *)generic;
+    asm volatile("" : "+v"(addr));
+    return (LDS_AS T *)(size_t)addr;
+}
+
+// pure lane shift (no accumulate): lanes without a source read 0
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// order-preserving key of a float32 that is not NaN
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+
+}  // namespace shp

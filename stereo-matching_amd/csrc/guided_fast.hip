@@ -23,61 +23,9 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "census_dev.hpp"
+#include "fast_common.hpp"
 
 namespace shp {
-
-struct FastArgs {
-    const void *lw;         // left census words
-    const void *rw;         // right census words
-    const float *guide;     // [H][W]
-    const double *mean;     // [H][W] box mean of the guide
-    const double *invden;   // [H][W] 1 / (var + eps32)
-    const float *gmax;      // max |guide| (device scalar)
-    uint64_t *keys;         // [H][W] packed (cost, d)
-    float *q_out;           // optional [D][H][W]
-    int H, W, D;
-    int d_begin, d_end;     // disparity range of the launch
-    int n_slices;           // gridDim.z; slice z handles every n_slices-th chunk of the range
-    int radius;             // census radius
-    float unit;             // value of one cost unit
-    uint32_t large_units;   // `large` in cost units
-    int atomic_out;
-};
-
-#define DPP_WAVE_SHL1 0x130
-#define DPP_WAVE_SHR1 0x138
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-
-// LDS pointer whose value the optimiser cannot see through: accesses relative to it keep their
-// small row offsets as instruction immediates instead of re-adding the (> 64 KiB) array base.
-#define LDS_AS __attribute__((address_space(3)))
-template <typename T>
-__device__ __forceinline__ LDS_AS T *lds_lane_ptr(T *generic) {
-    unsigned addr = (unsigned)(size_t)(LDS_AS T *)generic;
-    asm volatile("" : "+v"(addr));
-    return (LDS_AS T *)(size_t)addr;
-}
-
-// pure lane shift (no accumulate): lanes without a source read 0
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov_f(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-
-// order-preserving key of a float32 that is not NaN
-__device__ __forceinline__ uint32_t ordered_bits(float f) {
-    const uint32_t b = __float_as_uint(f);
-    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
-}
 
 // LDS image of one tile (pointers into the dynamic shared segment)
 template <typename WordT>
@@ -138,6 +86,13 @@ __device__ __forceinline__ void fast_disparity_pass(
     // One group of WIN consecutive tile rows.  STEADY groups start at base >= 4r, where both box
     // stages are live for every row; the first two groups resolve their stage tests at compile
     // time (base is then the literal 0 or WIN), so no group has a branch in its body.
+    // The operands a row needs first are fetched one row ahead; the head of the next row is carried
+    // from one row group into the next so that no group starts by waiting for its own loads.
+    struct RowHead {
+        WordT L, R; int k; float glo;
+    };
+    RowHead cur;
+    bool have_head = false;
     auto row_group = [&](const int base, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         // lane pointers of this group: the per-row accesses below are then immediate offsets
@@ -153,9 +108,6 @@ __device__ __forceinline__ void fast_disparity_pass(
         // The operands a row needs first (census words, guide split) are fetched one row ahead;
         // the ones it needs late (guide mean, 1/den, guide of the output row) at the start of the
         // row itself, so that every LDS / L2 latency overlaps arithmetic.
-        struct RowHead {
-            WordT L, R; int k; float glo;
-        };
         auto fetch_head = [&](int k) {
             RowHead r;
             r.L = Lg[k * 64];
@@ -164,7 +116,7 @@ __device__ __forceinline__ void fast_disparity_pass(
             r.R = rp[(size_t)row_of(min(base + k, NI - 1)) * W];
             return r;
         };
-        RowHead cur = fetch_head(0);
+        if (!have_head) { cur = fetch_head(0); have_head = true; }
 #pragma unroll
         for (int k = 0; k < WIN; ++k) {
             const int i = base + k;
@@ -174,6 +126,11 @@ __device__ __forceinline__ void fast_disparity_pass(
             float g[WIN];
 #pragma unroll
             for (int u = 0; u < WIN; ++u) g[u] = goutg[k * 64 + u];
+            // the row leaving the window [i - 2r, i] retires first, so that its ring registers are free
+            // before the new row's values are formed (no register copies at the loop edge)
+            C1 -= pr[k];
+            I2 -= kr[k];
+            F2 -= gr[k];
             // 1. cost in units; k*p and g_lo*p
             const uint32_t fs = field_sum((WordT)(cur.L ^ cur.R));
             uint32_t p;
@@ -188,9 +145,9 @@ __device__ __forceinline__ void fast_disparity_pass(
             const int kp = __mul24(cur.k, (int)p);
             const float gl = cur.glo * (float)p;
             // 2. vertical running sums over rows [i - 2r, i]
-            C1 += p - pr[k];
-            I2 += kp - kr[k];
-            F2 += gl - gr[k];
+            C1 += p;
+            I2 += kp;
+            F2 += gl;
             pr[k] = p; kr[k] = kp; gr[k] = gl;
             if (STEADY || i >= HALO) {
                 // 3. sums over lanes [l - 2r, l]: the box sums of column x - r
@@ -212,8 +169,8 @@ __device__ __forceinline__ void fast_disparity_pass(
                 const double bv = fma(-av, mG, s1d * ia);
                 // 5. vertical running sums over stage-1 rows [j - 2r, j]
                 const int k2 = (k + 1) % WIN;
-                A += av - ar[k2];
-                B += bv - br[k2];
+                A = (A - ar[k2]) + av;
+                B = (B - br[k2]) + bv;
                 ar[k2] = av;
                 br[k2] = bv;
                 if (STEADY || i >= 2 * HALO) {

@@ -1,0 +1,524 @@
+// Two-columns-per-lane variant of the fast fused census-cost + guided-filter + WTA kernel.
+//
+// Same arithmetic as guided_fast.hip (exact 32-bit stage-1 sums with the guide split
+// G = k * 2^-s + g_lo, float64 a / b and vertical sums, self-referenced float32 stage 2), but a
+// wavefront covers 128 image columns: lane l owns the adjacent columns 2l ("slot 0") and
+// 2l + 1 ("slot 1").  That
+//  * shrinks the horizontal halo from 4r of 64 columns to 4r of 128, and
+//  * shares the lane chains of the box sums between the two slots.  A window of 2r + 1
+//    consecutive columns ending in slot 0 of lane l holds r + 1 slot-0 values (lanes l-r..l) and
+//    r slot-1 values (lanes l-r..l-1); ending in slot 1 it holds r + 1 slot-1 values and r
+//    slot-0 values (lanes l-r+1..l).  One chain per slot of r shifted adds yields both the
+//    r-term and the (r+1)-term partial sums, and one more add per slot combines them:
+//    2r + 2 instructions for two columns instead of 4r.
+// Workgroups are 8 wavefronts (the per-lane state is twice as large), each marching down the
+// tile rows for one disparity at a time.
+#include <cstdlib>
+#include <type_traits>
+
+#include "fast_common.hpp"
+
+namespace shp {
+
+template <typename WordT>
+struct PairLds {
+    double *mG;      // [NJ][128] box mean of the guide
+    uint64_t *key;   // [TH][128] packed (cost, d)
+    double *iay1;    // [NJ] 1 / (rows of the clipped window), 0 outside the image
+    float *cy2;      // [TH] rows of the clipped window of the output rows (0 outside the image)
+    double *invtab;  // [16] 1/n
+    WordT *L;        // [NI][128] left census words
+    float *inv;      // [NJ][128] 1 / ((var + eps) * window area)
+    float *glo;      // [NI][128] guide - k * 2^-s
+    float *gout;     // [TH][128] (+pad) guide at the output pixels
+    int *next_d;     // [0] next disparity to hand out, [1] lowest disparity whose costs are all `large`
+    short *k;        // [NI][128] round(guide * 2^s)
+};
+
+template <typename T>
+using Pair = T __attribute__((ext_vector_type(2)));  // the two slots of a lane, loaded with one LDS read
+
+// Per-lane constants of the two slots.
+struct PairLane {
+    int x[2];             // image column of the slot's cost and of its final output
+    bool x_in[2];         // column inside the image
+    bool x_valid[2];      // census centre valid in x
+    double invAX1[2];     // 1 / (columns of the clipped stage-1 window), 0 outside the image
+    float cxf[2];         // columns of the clipped output window
+    int c1;               // tile column of slot 0's stage-1 result, clamped to >= 0
+};
+
+// One disparity of one tile.  MODE 0: general.  MODE 1: every row the tile touches is inside the
+// image and has a valid census centre, so the per-row tests vanish.  MODE 2: in addition every
+// column of the tile (halo included) has a valid match at this disparity and full filter
+// windows, and the tile's inputs are finite: no cost select, constant window area, no NaN test.
+template <int RG, bool WORD64, int TH, bool QOUT, int MODE>
+__device__ __forceinline__ void pair_disparity_pass(
+    const FastArgs &a, const PairLds<typename std::conditional<WORD64, uint64_t, uint32_t>::type> &t, const int d,
+    const int lane, const int ty0, const PairLane &pl, const double inv_scale_d) {
+    constexpr int WIN = 2 * RG + 1;
+    constexpr int HALO = 2 * RG;
+    constexpr int NI = TH + 4 * RG;
+    constexpr int TC = 128;
+    constexpr bool INTERIOR = MODE >= 1;
+    constexpr bool LEAN = MODE == 2;
+    using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
+    const int H = a.H, W = a.W, R = a.radius;
+    const WordT *rw = static_cast<const WordT *>(a.rw);
+    const int iv_lo = max(R - (ty0 - HALO), 0), iv_hi = min(H - R - (ty0 - HALO), NI);
+    const int ii_lo = max(-(ty0 - HALO), 0), ii_hi = min(H - (ty0 - HALO), NI);
+
+    uint32_t large_lane[2];
+    bool xd_valid[2];
+    unsigned roff[2];  // byte offset of the right census word inside its row
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        large_lane[j] = pl.x_in[j] ? a.large_units : 0u;
+        xd_valid[j] = pl.x_valid[j] && (pl.x[j] - d >= R);
+        roff[j] = (unsigned)min(max(pl.x[j] - d, 0), W - 1) * (unsigned)sizeof(WordT);
+    }
+
+    uint32_t C1[2] = {0u, 0u};
+    int I2[2] = {0, 0};
+    float F2[2] = {0.f, 0.f};
+    double A[2] = {0.0, 0.0}, B[2] = {0.0, 0.0};
+    uint32_t pr[2][WIN];
+    int kr[2][WIN];
+    float gr[2][WIN];
+    double ar[2][WIN], br[2][WIN];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) { pr[j][k] = 0u; kr[j][k] = 0; gr[j][k] = 0.f; ar[j][k] = 0.0; br[j][k] = 0.0; }
+
+    auto row_of = [&](int i) -> int {
+        int y = ty0 - HALO + i;
+        return INTERIOR ? y : min(max(y, 0), H - 1);
+    };
+    double ia_interior[2];
+    float area_interior[2], rcp_interior[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        ia_interior[j] = pl.invAX1[j] * (1.0 / (double)WIN);
+        area_interior[j] = pl.cxf[j] * (float)WIN;
+        rcp_interior[j] = __builtin_amdgcn_rcpf(area_interior[j]);
+    }
+    // full windows: the same reciprocal instruction as the other modes use, on a value the
+    // compiler cannot fold, so that every mode rounds a pixel's quotient identically
+    float area_full = (float)(WIN * WIN);
+    asm volatile("" : "+v"(area_full));
+    const float rcp_full = __builtin_amdgcn_rcpf(area_full);
+    constexpr double ia_full = 1.0 / (double)(WIN * WIN);
+
+    // Operands of a row are fetched one row ahead; the head of the next row is carried from one
+    // row group into the next so that no group starts by waiting for its own loads.
+    struct RowHead {
+        WordT L[2]; int k[2]; float glo[2]; double mG[2]; float inv_f[2];
+    };
+    RowHead cur;
+    bool have_head = false;
+    // right census words come from global memory (L2): they are requested RPF rows ahead
+    constexpr int RPF = 3;
+    WordT rq[RPF][2];
+    auto load_right = [&](int i, WordT *dst) {
+        const char *rrow = reinterpret_cast<const char *>(rw + (size_t)row_of(min(i, NI - 1)) * W);
+        dst[0] = *reinterpret_cast<const WordT *>(rrow + roff[0]);
+        dst[1] = *reinterpret_cast<const WordT *>(rrow + roff[1]);
+    };
+#pragma unroll
+    for (int u = 0; u < RPF; ++u) load_right(u, rq[u]);
+    auto row_group = [&](const int base, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        LDS_AS const Pair<WordT> *Lg = lds_lane_ptr(reinterpret_cast<const Pair<WordT> *>(t.L + base * TC + 2 * lane));
+        LDS_AS const uint32_t *kg = lds_lane_ptr(reinterpret_cast<const uint32_t *>(t.k + base * TC + 2 * lane));
+        LDS_AS const Pair<float> *glog = lds_lane_ptr(reinterpret_cast<const Pair<float> *>(t.glo + base * TC + 2 * lane));
+        LDS_AS const double *mGg = lds_lane_ptr(t.mG + (base - HALO) * TC + pl.c1);
+        LDS_AS const float *invg = lds_lane_ptr(t.inv + (base - HALO) * TC + pl.c1);
+        LDS_AS const Pair<float> *goutg = lds_lane_ptr(reinterpret_cast<const Pair<float> *>(t.gout + (base - 2 * HALO) * TC + 2 * lane));
+        LDS_AS uint64_t *keyg = lds_lane_ptr(t.key + (base - 2 * HALO) * TC + 2 * lane);
+        LDS_AS const double *iay1g = lds_lane_ptr(t.iay1 + (base - HALO));
+        LDS_AS const float *cy2g = lds_lane_ptr(t.cy2 + (base - 2 * HALO));
+        auto fetch_head = [&](int k) {
+            RowHead r;
+            const Pair<WordT> lp = Lg[k * (TC / 2)];
+            const uint32_t kk = kg[k * (TC / 2)];
+            const Pair<float> gp = glog[k * (TC / 2)];
+            r.L[0] = lp.x; r.L[1] = lp.y;
+            r.k[0] = (int)(short)(kk & 0xffffu); r.k[1] = (int)kk >> 16;
+            r.glo[0] = gp.x; r.glo[1] = gp.y;
+            r.mG[0] = mGg[k * TC]; r.mG[1] = mGg[k * TC + 1];
+            r.inv_f[0] = invg[k * TC]; r.inv_f[1] = invg[k * TC + 1];
+            return r;
+        };
+        if (!have_head) { cur = fetch_head(0); have_head = true; }
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const int i = base + k;
+            const RowHead nxt = fetch_head(k + 1);
+            const WordT Rcur[2] = {rq[0][0], rq[0][1]};
+#pragma unroll
+            for (int u = 0; u + 1 < RPF; ++u) { rq[u][0] = rq[u + 1][0]; rq[u][1] = rq[u + 1][1]; }
+            load_right(i + RPF, rq[RPF - 1]);
+            const double mG[2] = {cur.mG[0], cur.mG[1]};
+            const float inv_f[2] = {cur.inv_f[0], cur.inv_f[1]};
+            float g[2 * RG + 2];  // guide of the output row at tile columns 2l .. 2l + 2r + 1
+#pragma unroll
+            for (int u = 0; u <= RG; ++u) {
+                const Pair<float> gp = goutg[k * (TC / 2) + u];
+                g[2 * u] = gp.x; g[2 * u + 1] = gp.y;
+            }
+            // 2a. the row leaving the window [i - 2r, i] retires first, so that its ring registers are
+            //     free before the new row's values are formed (no register copies at the loop edge)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                C1[j] -= pr[j][k];
+                I2[j] -= kr[j][k];
+                F2[j] -= gr[j][k];
+            }
+            // 1. costs in units; k*p and g_lo*p; 2b. the new row enters the vertical running sums
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t fs = field_sum((WordT)(cur.L[j] ^ Rcur[j]));
+                uint32_t p;
+                if (LEAN) {
+                    p = fs;
+                } else if (INTERIOR) {
+                    p = xd_valid[j] ? fs : large_lane[j];
+                } else {
+                    const bool rowv = i >= iv_lo && i < iv_hi;
+                    const bool rowi = i >= ii_lo && i < ii_hi;
+                    p = (rowv && xd_valid[j]) ? fs : large_lane[j];
+                    p = rowi ? p : 0u;
+                }
+                const int kp = __mul24(cur.k[j], (int)p);
+                const float gl = cur.glo[j] * (float)p;
+                C1[j] += p;
+                I2[j] += kp;
+                F2[j] += gl;
+                pr[j][k] = p; kr[j][k] = kp; gr[j][k] = gl;
+            }
+            if (STEADY || i >= HALO) {
+                // 3. sums over the 2r + 1 columns ending in each slot: the box sums of column x - r
+                uint32_t e1 = C1[0], o1 = C1[1], e1r = C1[0], o1r = C1[1];
+                int ei = I2[0], oi = I2[1], eir = I2[0], oir = I2[1];
+                float ef_ = F2[0], of_ = F2[1], efr = F2[0], ofr = F2[1];
+#pragma unroll
+                for (int u = 0; u < RG; ++u) {
+                    e1r = e1; o1r = o1; eir = ei; oir = oi; efr = ef_; ofr = of_;   // partial sums of u + 1 lanes
+                    e1 = C1[0] + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)e1);
+                    o1 = C1[1] + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)o1);
+                    ei = I2[0] + dpp_i<DPP_WAVE_SHR1>(ei);
+                    oi = I2[1] + dpp_i<DPP_WAVE_SHR1>(oi);
+                    ef_ = F2[0] + dpp_f<DPP_WAVE_SHR1>(ef_);
+                    of_ = F2[1] + dpp_f<DPP_WAVE_SHR1>(of_);
+                }
+                uint32_t s1[2];
+                int si[2];
+                float sf[2];
+                s1[0] = e1 + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)o1r);
+                si[0] = ei + dpp_i<DPP_WAVE_SHR1>(oir);
+                sf[0] = ef_ + dpp_f<DPP_WAVE_SHR1>(ofr);
+                s1[1] = o1 + e1r;
+                si[1] = oi + eir;
+                sf[1] = of_ + efr;
+                // 4. a, b; 5. their vertical running sums over stage-1 rows [j - 2r, j]
+                const int k2 = (k + 1) % WIN;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    A[j] -= ar[j][k2];
+                    B[j] -= br[j][k2];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const double ia = LEAN ? ia_full : INTERIOR ? ia_interior[j] : iay1g[k] * pl.invAX1[j];
+                    const double s1d = (double)s1[j];
+                    const double u = fma(-mG[j], s1d, fma((double)si[j], inv_scale_d, (double)sf[j]));
+                    const double av = u * (double)inv_f[j];
+                    const double bv = fma(-av, mG[j], s1d * ia);
+                    A[j] += av;
+                    B[j] += bv;
+                    ar[j][k2] = av;
+                    br[j][k2] = bv;
+                }
+                if (STEADY || i >= 2 * HALO) {
+                    // 6. sums over the 2r + 1 stage-1 columns starting in each slot
+                    const int o = i - 2 * HALO;
+                    float E[2], Af[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        E[j] = (float)fma(A[j], (double)g[j], B[j]);  // column's own-guide output
+                        Af[j] = (float)A[j];
+                    }
+                    float ee = E[0], eo = E[1], eer = E[0], eor = E[1];
+                    float ae[RG + 1], ao[RG + 1];
+                    ae[0] = Af[0]; ao[0] = Af[1];
+#pragma unroll
+                    for (int u = 1; u <= RG; ++u) {
+                        eer = ee; eor = eo;
+                        ee = E[0] + dpp_f<DPP_WAVE_SHL1>(ee);
+                        eo = E[1] + dpp_f<DPP_WAVE_SHL1>(eo);
+                        ae[u] = dpp_mov_f<DPP_WAVE_SHL1>(ae[u - 1]);   // A of tile column 2(l + u)
+                        ao[u] = dpp_mov_f<DPP_WAVE_SHL1>(ao[u - 1]);   // A of tile column 2(l + u) + 1
+                    }
+                    float se[2], dsum[2];
+                    se[0] = ee + eor;
+                    se[1] = eo + dpp_f<DPP_WAVE_SHL1>(eer);
+                    // sum_j A_j * (G(x) - G_j) over the other 2r columns of each window
+                    dsum[0] = ao[0] * (g[0] - g[1]);
+                    dsum[1] = 0.f;
+#pragma unroll
+                    for (int u = 1; u <= RG; ++u) {
+                        dsum[0] = fmaf(ae[u], g[0] - g[2 * u], dsum[0]);
+                        if (u < RG) dsum[0] = fmaf(ao[u], g[0] - g[2 * u + 1], dsum[0]);
+                        dsum[1] = fmaf(ae[u], g[1] - g[2 * u], dsum[1]);
+                        dsum[1] = fmaf(ao[u], g[1] - g[2 * u + 1], dsum[1]);
+                    }
+                    // 7. q and the running WTA
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float t32 = se[j] + dsum[j];
+                        const float areaf = LEAN ? area_full : INTERIOR ? area_interior[j] : cy2g[k] * pl.cxf[j];
+                        const float r0 = LEAN ? rcp_full : INTERIOR ? rcp_interior[j] : __builtin_amdgcn_rcpf(areaf);
+                        const float q0 = t32 * r0;
+                        float qf = fmaf(fmaf(-q0, areaf, t32), r0, q0) * a.unit;
+                        if (QOUT) {
+                            const int yo = ty0 + o;
+                            const int tc = 2 * lane + j;
+                            if (tc >= HALO && tc < TC - HALO && pl.x[j] < W && yo < H)
+                                a.q_out[((size_t)d * H + yo) * W + pl.x[j]] = qf;
+                        }
+                        if (!LEAN) qf = (qf == qf) ? qf : __int_as_float(0x7f800000);
+                        const unsigned long long key = ((unsigned long long)ordered_bits(qf) << 32) | (uint32_t)d;
+#ifdef PAIR_ABLATE_ATOMIC
+                        if (key == 12345ull)
+#endif
+                        __hip_atomic_fetch_min(reinterpret_cast<LDS_AS unsigned long long *>(keyg + k * TC + j), key,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            cur = nxt;
+        }
+    };
+    static_assert(2 * WIN >= 2 * HALO, "two peeled groups cover the start-up rows");
+    row_group(0, std::false_type{});
+    row_group(WIN, std::false_type{});
+    for (int base = 2 * WIN; base < NI; base += WIN) row_group(base, std::true_type{});
+}
+
+template <int RG, bool WORD64, int TH, int NW, bool QOUT>
+__global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) {
+    constexpr int WIN = 2 * RG + 1;
+    constexpr int HALO = 2 * RG;
+    constexpr int NI = TH + 4 * RG;
+    constexpr int NJ = TH + 2 * RG;
+    constexpr int TC = 128;
+    constexpr int TWV = TC - 4 * RG;
+    static_assert(NI % WIN == 0, "the row loop is unrolled by the window length without a tail");
+    using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char *sp = smem_raw;
+    PairLds<WordT> t;
+    t.mG = reinterpret_cast<double *>(sp); sp += sizeof(double) * NJ * TC;
+    t.key = reinterpret_cast<uint64_t *>(sp); sp += sizeof(uint64_t) * TH * TC;
+    t.iay1 = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((NJ + 1) / 2 * 2);
+    t.cy2 = reinterpret_cast<float *>(sp); sp += sizeof(double) * ((TH + 1) / 2 * 2);
+    t.invtab = reinterpret_cast<double *>(sp); sp += sizeof(double) * 16;
+    t.L = reinterpret_cast<WordT *>(sp); sp += sizeof(WordT) * NI * TC;
+    t.inv = reinterpret_cast<float *>(sp); sp += sizeof(float) * NJ * TC;
+    t.glo = reinterpret_cast<float *>(sp); sp += sizeof(float) * NI * TC;
+    t.gout = reinterpret_cast<float *>(sp); sp += sizeof(float) * (TH * TC + 16);
+    t.next_d = reinterpret_cast<int *>(sp); sp += 16;
+    t.k = reinterpret_cast<short *>(sp);
+
+    const int lane = threadIdx.x & 63;
+    const int H = a.H, W = a.W;
+    const int tx0 = blockIdx.x * TWV, ty0 = blockIdx.y * TH;
+    const WordT *lw = static_cast<const WordT *>(a.lw);
+
+    const float gmax = *a.gmax;
+    int kmax = (int)(2147483647u / ((uint32_t)(WIN * WIN) * max(a.large_units, 1u)));
+    kmax = min(kmax, 32767);
+    int sh = 0;
+    if (gmax > 0.f && gmax < 3.0e38f) sh = min(max(ilogbf((float)kmax / gmax), -120), 120);
+    const float scale_f = ldexpf(1.f, sh);
+    const float inv_scale_f = ldexpf(1.f, -sh);
+    const double inv_scale_d = (double)inv_scale_f;
+
+    if (threadIdx.x == 0) { t.next_d[0] = 0; t.next_d[1] = 0x7fffffff; t.next_d[2] = 0; }
+    __syncthreads();
+    bool finite_in = gmax < 3.0e38f;
+    for (int idx = threadIdx.x; idx < NI * TC; idx += NW * 64) {
+        int i = idx / TC, c = idx % TC;
+        int gy = ty0 - HALO + i, gx = tx0 - HALO + c;
+        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        float g = in ? a.guide[(size_t)gy * W + gx] : 0.f;
+        finite_in = finite_in && fabsf(g) <= 3.0e38f;
+        int kk = __float2int_rn(g * scale_f);
+        t.k[idx] = (short)kk;
+        t.glo[idx] = fmaf(-(float)kk, inv_scale_f, g);
+        t.L[idx] = in ? lw[(size_t)gy * W + gx] : WordT(0);
+        int o = i - HALO;
+        if (o >= 0 && o < TH) t.gout[o * TC + c] = g;
+    }
+    for (int idx = threadIdx.x; idx < NJ * TC; idx += NW * 64) {
+        int j = idx / TC, c = idx % TC;
+        int gy = ty0 - RG + j, gx = tx0 - HALO + c;
+        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const double mg = in ? a.mean[(size_t)gy * W + gx] : 0.0;
+        t.mG[idx] = mg;
+        const int cyy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1, cxx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
+        const float iv = in ? (float)(a.invden[(size_t)gy * W + gx] / (double)(cyy * cxx)) : 0.f;
+        t.inv[idx] = iv;
+        finite_in = finite_in && fabs(mg) <= 1.0e300 && fabsf(iv) <= 3.0e38f;
+    }
+    if (!finite_in) t.next_d[2] = 1;  // (after the barrier below it reads 0 unless some thread saw a non-finite input)
+    for (int idx = threadIdx.x; idx < TH * TC; idx += NW * 64) t.key[idx] = SHP_KEY_INIT;
+    if (threadIdx.x < 16) t.gout[TH * TC + threadIdx.x] = 0.f;
+    for (int j = threadIdx.x; j < NJ; j += NW * 64) {
+        int y = ty0 - RG + j;
+        t.iay1[j] = (y >= 0 && y < H) ? 1.0 / (double)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.0;
+    }
+    for (int o = threadIdx.x; o < TH; o += NW * 64) {
+        int y = ty0 + o;
+        t.cy2[o] = (y < H) ? (float)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.f;
+    }
+    if (threadIdx.x <= WIN) t.invtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
+    __syncthreads();
+
+    const int R = a.radius;
+    PairLane pl;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tc = 2 * lane + j;       // tile column of the slot
+        const int x = tx0 - HALO + tc;     // column of the slot's cost and of its final output
+        const int x1 = x - RG;             // column of the slot's stage-1 result (a, b)
+        const bool x_in = x >= 0 && x < W;
+        const bool x1_in = x1 >= 0 && x1 < W && tc >= RG;
+        const int cx = x_in ? (min(x + RG, W - 1) - max(x - RG, 0) + 1) : 0;
+        const int cx1 = x1_in ? (min(x1 + RG, W - 1) - max(x1 - RG, 0) + 1) : 0;
+        pl.x[j] = x;
+        pl.x_in[j] = x_in;
+        pl.x_valid[j] = x_in && x >= R && x < W - R;
+        pl.invAX1[j] = t.invtab[cx1];
+        pl.cxf[j] = (float)cx;
+    }
+    pl.c1 = max(2 * lane - RG, 0);
+    const bool interior = (ty0 - HALO >= R) && (ty0 + TH + HALO <= H - R);
+    // columns tx0 - 2r .. tx0 - 2r + 127: full filter windows, valid census centres, finite inputs
+    const int xlo = tx0 - HALO, xhi = tx0 - HALO + TC - 1;
+    const int xmargin = max(R, 2 * RG);
+    const bool lean_tile = !QOUT && interior && xlo >= xmargin && xhi <= W - 1 - xmargin && t.next_d[2] == 0;
+    const int n_disp = a.d_end - a.d_begin;
+
+    for (;;) {
+        int dn = 0;
+        if (lane == 0) dn = atomicAdd(t.next_d, 1);
+        dn = __builtin_amdgcn_readfirstlane(dn);
+        const int d = a.d_begin + dn * a.n_slices + (int)blockIdx.z;
+        if (d >= a.d_end || dn >= n_disp) break;
+        // every column of the tile lies left of the first valid match: all costs are `large`
+        if (!QOUT && tx0 - HALO + (TC - 1) - d < R) {
+            if (lane == 0) atomicMin(&t.next_d[1], d);
+            continue;
+        }
+        if (lean_tile && xlo - d >= R)
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 2>(a, t, d, lane, ty0, pl, inv_scale_d);
+        else if (interior)
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 1>(a, t, d, lane, ty0, pl, inv_scale_d);
+        else
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 0>(a, t, d, lane, ty0, pl, inv_scale_d);
+    }
+    __syncthreads();
+    const int skipped_d = t.next_d[1];
+    const float large_f = (float)a.large_units * a.unit;
+    for (int idx = threadIdx.x; idx < TH * TC; idx += NW * 64) {
+        int o = idx / TC, c = idx % TC;
+        int gy = ty0 + o, gx = tx0 - HALO + c;
+        if (c >= HALO && c < TC - HALO && gy < H && gx < W) {
+            uint64_t key = t.key[idx];
+            if (skipped_d != 0x7fffffff) {
+                const uint64_t kl = make_key(large_f, (uint32_t)skipped_d);
+                key = kl < key ? kl : key;
+            }
+            if (a.atomic_out) atomicMin(reinterpret_cast<unsigned long long *>(&a.keys[(size_t)gy * W + gx]),
+                                        (unsigned long long)key);
+            else a.keys[(size_t)gy * W + gx] = key;
+        }
+    }
+}
+
+// Tile height per (guided radius, census word size): the largest TH with TH + 4r a multiple
+// of 2r + 1 whose tile image fits the 160 KiB LDS.
+template <int RG, bool WORD64>
+struct PairTile {
+    static constexpr size_t bytes(int th) {
+        const size_t ni = th + 4 * RG, nj = th + 2 * RG, tc = 128, w = WORD64 ? 8 : 4;
+        return sizeof(double) * nj * tc + sizeof(uint64_t) * th * tc + sizeof(double) * ((nj + 1) / 2 * 2) +
+               sizeof(double) * ((th + 1) / 2 * 2) + sizeof(double) * 16 + w * ni * tc + sizeof(float) * nj * tc +
+               sizeof(float) * ni * tc + sizeof(float) * (th * tc + 16) + 16 + sizeof(short) * (ni + 1) * tc;  // one pad row: rows are fetched one ahead
+    }
+    static constexpr int best() {
+        int th = 0;
+        for (int c = 1; c < 200; ++c)
+            if ((c + 4 * RG) % (2 * RG + 1) == 0 && bytes(c) <= 160 * 1024) th = c;
+        return th;
+    }
+    static constexpr int TH = best();
+};
+
+#ifndef FP_NW
+#define FP_NW 8
+#endif
+
+template <int RG, bool WORD64, bool QOUT>
+static int launch_pair_q(const FastArgs &a, hipStream_t s) {
+    constexpr int TH = PairTile<RG, WORD64>::TH;
+    static_assert(TH >= 2 * RG + 1, "tile too small");
+    constexpr size_t smem = PairTile<RG, WORD64>::bytes(TH);
+    static_assert(smem <= 160 * 1024, "tile image exceeds the LDS");
+    auto kern = fused_guided_pair_kernel<RG, WORD64, TH, FP_NW, QOUT>;
+    SHP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem));
+    dim3 grid(ceil_div(a.W, 128 - 4 * RG), ceil_div(a.H, TH), a.n_slices);
+    hipLaunchKernelGGL(kern, grid, dim3(FP_NW * 64), smem, s, a);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+bool fused_pair_supported(const CensusCfg &cfg, int guided_radius) {
+    return cfg.exact && guided_radius == 3 && !cfg.word64 && cfg.unit > 0.f;
+}
+
+int fused_pair_slices(int H, int W, int guided_radius, int n_disp) {
+    const int th = PairTile<3, false>::TH;
+    int tiles = ceil_div(W, 128 - 4 * guided_radius) * ceil_div(H, th);
+    int s = 1;
+    const char *e = getenv("STEREO_FAST_SLICES");
+    if (e) return atoi(e) > 0 ? atoi(e) : 1;
+    while (tiles * s < 1024 && s * FP_NW * 4 <= n_disp) s *= 2;
+    return s;
+}
+
+int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
+                             const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
+                             int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
+                             float *d_q_out, hipStream_t s) {
+    if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
+    FastArgs a;
+    memset(&a, 0, sizeof(a));
+    a.lw = d_lw; a.rw = d_rw; a.guide = d_guide; a.mean = d_mean; a.invden = d_invden; a.gmax = d_gmax;
+    a.keys = d_keys; a.q_out = d_q_out;
+    a.H = H; a.W = W; a.D = dmax; a.d_begin = d_begin; a.d_end = d_end;
+    a.n_slices = n_slices < 1 ? 1 : n_slices;
+    a.radius = cfg.radius; a.unit = cfg.unit;
+    a.large_units = (uint32_t)std::lround((double)cfg.large / (double)cfg.unit);
+    a.atomic_out = a.n_slices > 1;
+    if (guided_radius == 3 && !cfg.word64)
+        return d_q_out ? launch_pair_q<3, false, true>(a, s) : launch_pair_q<3, false, false>(a, s);
+    set_error("pair kernel: unsupported configuration");
+    return STEREO_EUNSUPPORTED;
+}
+
+}  // namespace shp

@@ -369,22 +369,33 @@ def test_radius8_filters_fused_golden(oracle):
     assert_wta_matches(d, c, g["disp_bilateral"], g["cost_bilateral"], lay, min_agree=0.95)
 
 
-def test_fast_and_general_fused_kernels_agree():
-    """The fast fused kernel (32-bit lane-shift box sums) against the general one (float64 sums
-    exchanged through LDS) on the same input: costs within 1e-6, disparities equal except near-ties."""
+def _with_kernel(mode, fn):
+    """Run fn with the fused guided kernel forced: 1 = general (float64 sums through LDS),
+    2 = fast with one column per lane, 0 = the default choice (two columns per lane where built)."""
     import _native
-    import stereo
-    from synth import synth_pair_gray
-    left, right, _ = synth_pair_gray(150, 333, 70, seed=33)
     lib = _native.lib()
     try:
-        _native.check(lib.stereo_debug_force_general_kernel(1))
-        d_gen, c_gen = stereo.compute_disparity(left, right, 70, guided_eps=0.0154, show_progress=False)
+        _native.check(lib.stereo_debug_force_general_kernel(mode))
+        return fn()
     finally:
         _native.check(lib.stereo_debug_force_general_kernel(0))
-    d_fast, c_fast = stereo.compute_disparity(left, right, 70, guided_eps=0.0154, show_progress=False)
-    assert rel_err(c_fast, c_gen) <= 1e-6
-    assert np.mean(d_fast == d_gen) >= 0.9995
+
+
+@pytest.mark.parametrize("shape", [(150, 333, 70), (61, 117, 40), (95, 260, 24)])
+def test_fused_kernel_variants_agree(shape):
+    """The three fused guided kernels on the same input: costs within 1e-6, disparities equal
+    except near-ties.  The shapes straddle the 116- and 52-column tile widths."""
+    import stereo
+    from synth import synth_pair_gray
+    h, w, dmax = shape
+    left, right, _ = synth_pair_gray(h, w, dmax, seed=33)
+    run = lambda: stereo.compute_disparity(left, right, dmax, guided_eps=0.0154, show_progress=False)
+    d_gen, c_gen = _with_kernel(1, run)
+    d_one, c_one = _with_kernel(2, run)
+    d_two, c_two = _with_kernel(0, run)
+    for d, c in ((d_one, c_one), (d_two, c_two)):
+        assert rel_err(c, c_gen) <= 1e-6
+        assert np.mean(d == d_gen) >= 0.9995
 
 
 @pytest.mark.parametrize("scale", [1.0, 255.0, 1.0 / 255.0, 4096.0])
