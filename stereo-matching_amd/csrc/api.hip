@@ -114,7 +114,7 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         if (d_begin == d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
         const bool pair = fused_pair_supported(cfg, p->guided_radius) && g_force_kernel == 0;
         const bool fast = fused_fast_supported(cfg, p->guided_radius) && g_force_kernel != 1;
-        const int slices = pair ? fused_pair_slices(H, W, p->guided_radius, d_end - d_begin)
+        const int slices = pair ? fused_pair_slices(H, W, p->guided_radius, cfg.word64 != 0, d_end - d_begin)
                            : fast ? fused_fast_slices(H, W, p->guided_radius, d_end - d_begin) : 1;
         if (slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
         const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();

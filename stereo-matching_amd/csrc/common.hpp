@@ -128,7 +128,7 @@ int launch_fused_guided(const void *d_lw, const void *d_rw, const CensusCfg *cfg
 
 // fast fused kernel (guided_fast.hip): exact census weights, float32 guide, guided radius <= 4
 bool fused_pair_supported(const CensusCfg &cfg, int guided_radius);
-int fused_pair_slices(int H, int W, int guided_radius, int n_disp);
+int fused_pair_slices(int H, int W, int guided_radius, bool word64, int n_disp);
 int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,

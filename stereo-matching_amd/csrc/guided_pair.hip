@@ -120,10 +120,21 @@ __device__ __forceinline__ void pair_disparity_pass(
     // right census words come from global memory (L2): they are requested RPF rows ahead
     constexpr int RPF = 3;
     WordT rq[RPF][2];
+    // buffer loads: the row offset travels in a scalar register and the lane's column offset in
+    // one 32-bit register, so no 64-bit address arithmetic is spent per row
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<WordT *>(rw), 0, (int)((size_t)H * W * sizeof(WordT)), 0x00020000);
     auto load_right = [&](int i, WordT *dst) {
-        const char *rrow = reinterpret_cast<const char *>(rw + (size_t)row_of(min(i, NI - 1)) * W);
-        dst[0] = *reinterpret_cast<const WordT *>(rrow + roff[0]);
-        dst[1] = *reinterpret_cast<const WordT *>(rrow + roff[1]);
+        const int soff = row_of(min(i, NI - 1)) * W * (int)sizeof(WordT);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (WORD64) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)roff[j], soff, 0);
+                dst[j] = (WordT)(((unsigned long long)(uint32_t)v[1] << 32) | (uint32_t)v[0]);
+            } else {
+                dst[j] = (WordT)(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)roff[j], soff, 0);
+            }
+        }
     };
 #pragma unroll
     for (int u = 0; u < RPF; ++u) load_right(u, rq[u]);
@@ -190,7 +201,8 @@ __device__ __forceinline__ void pair_disparity_pass(
                     p = (rowv && xd_valid[j]) ? fs : large_lane[j];
                     p = rowi ? p : 0u;
                 }
-                const int kp = __mul24(cur.k[j], (int)p);
+                int kp = __mul24(cur.k[j], (int)p);
+                asm volatile("" : "+v"(kp));  // one multiply: the running sum adds kp instead of re-deriving it
                 const float gl = cur.glo[j] * (float)p;
                 C1[j] += p;
                 I2[j] += kp;
@@ -289,9 +301,6 @@ __device__ __forceinline__ void pair_disparity_pass(
                         }
                         if (!LEAN) qf = (qf == qf) ? qf : __int_as_float(0x7f800000);
                         const unsigned long long key = ((unsigned long long)ordered_bits(qf) << 32) | (uint32_t)d;
-#ifdef PAIR_ABLATE_ATOMIC
-                        if (key == 12345ull)
-#endif
                         __hip_atomic_fetch_min(reinterpret_cast<LDS_AS unsigned long long *>(keyg + k * TC + j), key,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -487,12 +496,28 @@ static int launch_pair_q(const FastArgs &a, hipStream_t s) {
     return STEREO_OK;
 }
 
-bool fused_pair_supported(const CensusCfg &cfg, int guided_radius) {
-    return cfg.exact && guided_radius == 3 && !cfg.word64 && cfg.unit > 0.f;
+template <int RG, bool WORD64>
+static int launch_pair_t(const FastArgs &a, hipStream_t s) {
+    return a.q_out ? launch_pair_q<RG, WORD64, true>(a, s) : launch_pair_q<RG, WORD64, false>(a, s);
 }
 
-int fused_pair_slices(int H, int W, int guided_radius, int n_disp) {
-    const int th = PairTile<3, false>::TH;
+static int pair_tile_height(int guided_radius, bool word64) {
+    switch (guided_radius) {
+        case 1: return word64 ? PairTile<1, true>::TH : PairTile<1, false>::TH;
+        case 2: return word64 ? PairTile<2, true>::TH : PairTile<2, false>::TH;
+        case 3: return word64 ? PairTile<3, true>::TH : PairTile<3, false>::TH;
+        case 4: return word64 ? PairTile<4, true>::TH : PairTile<4, false>::TH;
+        default: return 0;
+    }
+}
+
+bool fused_pair_supported(const CensusCfg &cfg, int guided_radius) {
+    // radius 1 keeps one column per lane: its lane chains are too short for sharing them to pay
+    return cfg.exact && guided_radius >= 2 && guided_radius <= 4 && cfg.unit > 0.f;
+}
+
+int fused_pair_slices(int H, int W, int guided_radius, bool word64, int n_disp) {
+    const int th = pair_tile_height(guided_radius, word64);
     int tiles = ceil_div(W, 128 - 4 * guided_radius) * ceil_div(H, th);
     int s = 1;
     const char *e = getenv("STEREO_FAST_SLICES");
@@ -515,10 +540,14 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
     a.radius = cfg.radius; a.unit = cfg.unit;
     a.large_units = (uint32_t)std::lround((double)cfg.large / (double)cfg.unit);
     a.atomic_out = a.n_slices > 1;
-    if (guided_radius == 3 && !cfg.word64)
-        return d_q_out ? launch_pair_q<3, false, true>(a, s) : launch_pair_q<3, false, false>(a, s);
-    set_error("pair kernel: unsupported configuration");
-    return STEREO_EUNSUPPORTED;
+    const bool w64 = cfg.word64 != 0;
+    switch (guided_radius) {
+        case 1: return w64 ? launch_pair_t<1, true>(a, s) : launch_pair_t<1, false>(a, s);
+        case 2: return w64 ? launch_pair_t<2, true>(a, s) : launch_pair_t<2, false>(a, s);
+        case 3: return w64 ? launch_pair_t<3, true>(a, s) : launch_pair_t<3, false>(a, s);
+        case 4: return w64 ? launch_pair_t<4, true>(a, s) : launch_pair_t<4, false>(a, s);
+        default: set_error("fast fused guided kernel supports radius 1..4"); return STEREO_EUNSUPPORTED;
+    }
 }
 
 }  // namespace shp

@@ -225,16 +225,20 @@ def test_compute_disparity_edge_cases_golden(oracle):
     assert_wta_matches(d, c, r8["disp_guided"], r8["cost_guided"], layers_of(r8["dsi"], r8["left"]))
 
 
-@pytest.mark.parametrize("h,w,dmax,rg,seed", [(97, 211, 40, 3, 1), (33, 52, 17, 3, 2), (130, 300, 64, 2, 3),
-                                               (64, 53, 9, 4, 4), (31, 105, 30, 1, 5)])
-def test_compute_disparity_oracle_shapes(oracle, h, w, dmax, rg, seed):
-    """Tile-boundary shapes (tiles are 32 rows x (64 - 4r) columns) against the oracle."""
+@pytest.mark.parametrize("h,w,dmax,rg,seed,wct", [
+    (97, 211, 40, 3, 1, 4), (33, 52, 17, 3, 2, 4), (130, 300, 64, 2, 3, 4), (64, 53, 9, 4, 4, 4), (31, 105, 30, 1, 5, 4),
+    (100, 290, 48, 4, 6, 4), (100, 290, 40, 1, 7, 4), (90, 280, 32, 2, 8, 8), (90, 280, 32, 4, 9, 8), (120, 270, 24, 3, 10, 8)])
+def test_compute_disparity_oracle_shapes(oracle, h, w, dmax, rg, seed, wct):
+    """Tile-boundary shapes against the oracle, for every guided radius of the fused kernels and
+    both census word sizes.  The wider shapes contain tiles that take the kernels' interior modes
+    (tiles are about 30 rows x (128 - 4r) columns, or about 65 x (64 - 4r) for radius 1)."""
     import stereo
     from synth import synth_pair_gray
     left, right, _ = synth_pair_gray(h, w, dmax, seed)
-    dsi = oracle.wct_cost_volume(left, right, dmax)
+    dsi = oracle.wct_cost_volume(left, right, dmax, radius=wct)
     dref, cref, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, rg, 0.0154, want_layers=True)
-    d, c = stereo.compute_disparity(left, right, dmax, guided_radius=rg, guided_eps=0.0154, show_progress=False)
+    d, c = stereo.compute_disparity(left, right, dmax, wct_radius=wct, guided_radius=rg, guided_eps=0.0154,
+                                    show_progress=False)
     assert_wta_matches(d, c, dref, cref, layers)
 
 
