@@ -36,6 +36,26 @@ WORKLOADS = {
            "synthetic 3840x2160 pair, dmax=512, wct_radius=4, guided r=3 eps=0.0154"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
+# per-launch counter averages of a `rocprofv3 --pmc` run of this same command (tools/pmc_passes.sh)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "pair_pmc_per_launch.json")
+DOMINANT_KERNEL = "fused_guided_pair_kernel"
+
+
+def measured_hbm_traffic(workload: str):
+    """HBM bytes per launch of the dominant kernel from the committed counter summary: FETCH_SIZE and
+    WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes read.  None when the
+    summary is missing or was not taken on this workload."""
+    if workload != "motorcycle" or not os.path.exists(PMC_SUMMARY):
+        return None
+    try:
+        with open(PMC_SUMMARY) as fh:
+            summary = json.load(fh)
+        for name, counters in summary.items():
+            if DOMINANT_KERNEL in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+                return int((2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0)
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def parse_args():
@@ -190,11 +210,17 @@ def main() -> None:
                        "all-to-all + local (cost, d) min merge, gather to rank 0"},
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "fused_guided_kernel", "kernel_ms": round(kernel_avg_ms, 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": measured_hbm_traffic(args.workload) if world == 1 else None,
+                "kernel": DOMINANT_KERNEL, "kernel_ms": round(kernel_avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "DSI-equivalent: 8 B per pixel-disparity (a float32 cost volume written once and read "
-                        "once, which the fused kernel avoids) + 16 B per pixel; the kernel is VALU/LDS-bound",
+                "compulsory_frac": round(H * W * 16 / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                if kernel_avg_ms > 0 else None,
+                "note": "DSI-equivalent % of HBM peak: 8 B per pixel-disparity (a float32 cost volume written once "
+                        "and read once, which the fused kernel never materialises) + 16 B per pixel; traffic = "
+                        "measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate run of this "
+                        "command); the kernel is bound by vector-instruction issue (lane-shift and float64 ops), "
+                        "not by HBM",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -37,6 +37,10 @@ struct PairLds {
 
 template <typename T>
 using Pair = T __attribute__((ext_vector_type(2)));  // the two slots of a lane, loaded with one LDS read
+// The float32 arithmetic of the two slots is written on pairs: with two wavefronts per SIMD every
+// vector instruction costs one issue slot, so a packed instruction halves the cost of the pair.
+using f2 = Pair<float>;
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // Per-lane constants of the two slots.
 struct PairLane {
@@ -80,16 +84,18 @@ __device__ __forceinline__ void pair_disparity_pass(
 
     uint32_t C1[2] = {0u, 0u};
     int I2[2] = {0, 0};
-    float F2[2] = {0.f, 0.f};
+    f2 F2 = {0.f, 0.f};
     double A[2] = {0.0, 0.0}, B[2] = {0.0, 0.0};
     uint32_t pr[2][WIN];
     int kr[2][WIN];
-    float gr[2][WIN];
+    f2 gr[WIN];
     double ar[2][WIN], br[2][WIN];
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) gr[k] = f2{0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int k = 0; k < WIN; ++k) { pr[j][k] = 0u; kr[j][k] = 0; gr[j][k] = 0.f; ar[j][k] = 0.0; br[j][k] = 0.0; }
+        for (int k = 0; k < WIN; ++k) { pr[j][k] = 0u; kr[j][k] = 0; ar[j][k] = 0.0; br[j][k] = 0.0; }
 
     auto row_of = [&](int i) -> int {
         int y = ty0 - HALO + i;
@@ -108,12 +114,14 @@ __device__ __forceinline__ void pair_disparity_pass(
     float area_full = (float)(WIN * WIN);
     asm volatile("" : "+v"(area_full));
     const float rcp_full = __builtin_amdgcn_rcpf(area_full);
+    const f2 area_mode = LEAN ? f2{area_full, area_full} : f2{area_interior[0], area_interior[1]};
+    const f2 rcp_mode = LEAN ? f2{rcp_full, rcp_full} : f2{rcp_interior[0], rcp_interior[1]};
     constexpr double ia_full = 1.0 / (double)(WIN * WIN);
 
     // Operands of a row are fetched one row ahead; the head of the next row is carried from one
     // row group into the next so that no group starts by waiting for its own loads.
     struct RowHead {
-        WordT L[2]; int k[2]; float glo[2]; double mG[2]; float inv_f[2];
+        WordT L[2]; int k[2]; f2 glo; double mG[2]; float inv_f[2];
     };
     RowHead cur;
     bool have_head = false;
@@ -156,7 +164,7 @@ __device__ __forceinline__ void pair_disparity_pass(
             const Pair<float> gp = glog[k * (TC / 2)];
             r.L[0] = lp.x; r.L[1] = lp.y;
             r.k[0] = (int)(short)(kk & 0xffffu); r.k[1] = (int)kk >> 16;
-            r.glo[0] = gp.x; r.glo[1] = gp.y;
+            r.glo = gp;
             r.mG[0] = mGg[k * TC]; r.mG[1] = mGg[k * TC + 1];
             r.inv_f[0] = invg[k * TC]; r.inv_f[1] = invg[k * TC + 1];
             return r;
@@ -172,20 +180,18 @@ __device__ __forceinline__ void pair_disparity_pass(
             load_right(i + RPF, rq[RPF - 1]);
             const double mG[2] = {cur.mG[0], cur.mG[1]};
             const float inv_f[2] = {cur.inv_f[0], cur.inv_f[1]};
-            float g[2 * RG + 2];  // guide of the output row at tile columns 2l .. 2l + 2r + 1
+            f2 gp[RG + 1];  // guide of the output row at tile columns 2(l + u), 2(l + u) + 1
 #pragma unroll
-            for (int u = 0; u <= RG; ++u) {
-                const Pair<float> gp = goutg[k * (TC / 2) + u];
-                g[2 * u] = gp.x; g[2 * u + 1] = gp.y;
-            }
+            for (int u = 0; u <= RG; ++u) gp[u] = goutg[k * (TC / 2) + u];
             // 2a. the row leaving the window [i - 2r, i] retires first, so that its ring registers are
             //     free before the new row's values are formed (no register copies at the loop edge)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 C1[j] -= pr[j][k];
                 I2[j] -= kr[j][k];
-                F2[j] -= gr[j][k];
             }
+            F2 -= gr[k];
+            f2 pf;
             // 1. costs in units; k*p and g_lo*p; 2b. the new row enters the vertical running sums
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -203,17 +209,21 @@ __device__ __forceinline__ void pair_disparity_pass(
                 }
                 int kp = __mul24(cur.k[j], (int)p);
                 asm volatile("" : "+v"(kp));  // one multiply: the running sum adds kp instead of re-deriving it
-                const float gl = cur.glo[j] * (float)p;
+                pf[j] = (float)p;
                 C1[j] += p;
                 I2[j] += kp;
-                F2[j] += gl;
-                pr[j][k] = p; kr[j][k] = kp; gr[j][k] = gl;
+                pr[j][k] = p; kr[j][k] = kp;
+            }
+            {
+                const f2 gl = cur.glo * pf;
+                F2 += gl;
+                gr[k] = gl;
             }
             if (STEADY || i >= HALO) {
                 // 3. sums over the 2r + 1 columns ending in each slot: the box sums of column x - r
                 uint32_t e1 = C1[0], o1 = C1[1], e1r = C1[0], o1r = C1[1];
                 int ei = I2[0], oi = I2[1], eir = I2[0], oir = I2[1];
-                float ef_ = F2[0], of_ = F2[1], efr = F2[0], ofr = F2[1];
+                float ef_ = F2.x, of_ = F2.y, efr = F2.x, ofr = F2.y;
 #pragma unroll
                 for (int u = 0; u < RG; ++u) {
                     e1r = e1; o1r = o1; eir = ei; oir = oi; efr = ef_; ofr = of_;   // partial sums of u + 1 lanes
@@ -221,8 +231,8 @@ __device__ __forceinline__ void pair_disparity_pass(
                     o1 = C1[1] + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)o1);
                     ei = I2[0] + dpp_i<DPP_WAVE_SHR1>(ei);
                     oi = I2[1] + dpp_i<DPP_WAVE_SHR1>(oi);
-                    ef_ = F2[0] + dpp_f<DPP_WAVE_SHR1>(ef_);
-                    of_ = F2[1] + dpp_f<DPP_WAVE_SHR1>(of_);
+                    ef_ = F2.x + dpp_f<DPP_WAVE_SHR1>(ef_);
+                    of_ = F2.y + dpp_f<DPP_WAVE_SHR1>(of_);
                 }
                 uint32_t s1[2];
                 int si[2];
@@ -255,44 +265,49 @@ __device__ __forceinline__ void pair_disparity_pass(
                 if (STEADY || i >= 2 * HALO) {
                     // 6. sums over the 2r + 1 stage-1 columns starting in each slot
                     const int o = i - 2 * HALO;
-                    float E[2], Af[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        E[j] = (float)fma(A[j], (double)g[j], B[j]);  // column's own-guide output
-                        Af[j] = (float)A[j];
-                    }
-                    float ee = E[0], eo = E[1], eer = E[0], eor = E[1];
-                    float ae[RG + 1], ao[RG + 1];
-                    ae[0] = Af[0]; ao[0] = Af[1];
+                    f2 E, av[RG + 1];
+                    E.x = (float)fma(A[0], (double)gp[0].x, B[0]);  // each column's own-guide output
+                    E.y = (float)fma(A[1], (double)gp[0].y, B[1]);
+                    av[0].x = (float)A[0];
+                    av[0].y = (float)A[1];
+                    float ee = E.x, eo = E.y, eer = E.x, eor = E.y;
 #pragma unroll
                     for (int u = 1; u <= RG; ++u) {
                         eer = ee; eor = eo;
-                        ee = E[0] + dpp_f<DPP_WAVE_SHL1>(ee);
-                        eo = E[1] + dpp_f<DPP_WAVE_SHL1>(eo);
-                        ae[u] = dpp_mov_f<DPP_WAVE_SHL1>(ae[u - 1]);   // A of tile column 2(l + u)
-                        ao[u] = dpp_mov_f<DPP_WAVE_SHL1>(ao[u - 1]);   // A of tile column 2(l + u) + 1
+                        ee = E.x + dpp_f<DPP_WAVE_SHL1>(ee);
+                        eo = E.y + dpp_f<DPP_WAVE_SHL1>(eo);
+                        av[u].x = dpp_mov_f<DPP_WAVE_SHL1>(av[u - 1].x);   // A of tile column 2(l + u)
+                        av[u].y = dpp_mov_f<DPP_WAVE_SHL1>(av[u - 1].y);   // A of tile column 2(l + u) + 1
                     }
-                    float se[2], dsum[2];
-                    se[0] = ee + eor;
-                    se[1] = eo + dpp_f<DPP_WAVE_SHL1>(eer);
-                    // sum_j A_j * (G(x) - G_j) over the other 2r columns of each window
-                    dsum[0] = ao[0] * (g[0] - g[1]);
-                    dsum[1] = 0.f;
+                    f2 se;
+                    se.x = ee + eor;
+                    se.y = eo + dpp_f<DPP_WAVE_SHL1>(eer);
+                    // sum_j A_j * (G(x) - G_j) over the other 2r columns of each window.  Slot 0's window is
+                    // columns 2l .. 2l + 2r (its own term vanishes), slot 1's is 2l + 1 .. 2l + 2r + 1.
+                    f2 acc0 = av[0] * (gp[0].xx - gp[0]);
+                    f2 acc1 = av[1] * (gp[0].yy - gp[1]);
 #pragma unroll
-                    for (int u = 1; u <= RG; ++u) {
-                        dsum[0] = fmaf(ae[u], g[0] - g[2 * u], dsum[0]);
-                        if (u < RG) dsum[0] = fmaf(ao[u], g[0] - g[2 * u + 1], dsum[0]);
-                        dsum[1] = fmaf(ae[u], g[1] - g[2 * u], dsum[1]);
-                        dsum[1] = fmaf(ao[u], g[1] - g[2 * u + 1], dsum[1]);
-                    }
+                    for (int u = 1; u < RG; ++u) acc0 = fma2(av[u], gp[0].xx - gp[u], acc0);
+#pragma unroll
+                    for (int u = 2; u <= RG; ++u) acc1 = fma2(av[u], gp[0].yy - gp[u], acc1);
+                    f2 dsum;
+                    dsum.x = fmaf(av[RG].x, gp[0].x - gp[RG].x, acc0.x + acc0.y);
+                    dsum.y = acc1.x + acc1.y;
                     // 7. q and the running WTA
+                    const f2 t32 = se + dsum;
+                    f2 areav, r0v;
+                    if (INTERIOR) {
+                        areav = area_mode; r0v = rcp_mode;
+                    } else {
+                        const float cy = cy2g[k];
+                        areav = f2{cy * pl.cxf[0], cy * pl.cxf[1]};
+                        r0v = f2{__builtin_amdgcn_rcpf(areav.x), __builtin_amdgcn_rcpf(areav.y)};
+                    }
+                    const f2 q0 = t32 * r0v;
+                    const f2 qv = fma2(fma2(-q0, areav, t32), r0v, q0) * f2{a.unit, a.unit};
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const float t32 = se[j] + dsum[j];
-                        const float areaf = LEAN ? area_full : INTERIOR ? area_interior[j] : cy2g[k] * pl.cxf[j];
-                        const float r0 = LEAN ? rcp_full : INTERIOR ? rcp_interior[j] : __builtin_amdgcn_rcpf(areaf);
-                        const float q0 = t32 * r0;
-                        float qf = fmaf(fmaf(-q0, areaf, t32), r0, q0) * a.unit;
+                        float qf = qv[j];
                         if (QOUT) {
                             const int yo = ty0 + o;
                             const int tc = 2 * lane + j;
