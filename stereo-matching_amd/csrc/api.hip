@@ -66,8 +66,9 @@ static size_t dtype_size(int dt) { return dt == STEREO_DT_F64 ? 8 : (dt == STERE
 // layout of the fused workspace
 struct FusedWs {
     size_t words_bytes, plane_f64;
-    size_t off_lw, off_rw, off_mean, off_invden, off_gmax, total;
+    size_t off_lw, off_rw, off_mean, off_invden, off_gmax, off_mm, total;
 };
+constexpr int FUSED_MAX_DISPARITIES = 65536;  // per launch; sizes the per-layer min/max scratch of the median path
 static FusedWs fused_ws_layout(int H, int W, int wct_radius) {
     FusedWs w;
     size_t n = (size_t)H * W;
@@ -78,7 +79,8 @@ static FusedWs fused_ws_layout(int H, int W, int wct_radius) {
     w.off_mean = w.off_rw + w.words_bytes;
     w.off_invden = w.off_mean + w.plane_f64;
     w.off_gmax = w.off_invden + w.plane_f64;
-    w.total = w.off_gmax + 256;
+    w.off_mm = w.off_gmax + 256;
+    w.total = w.off_mm + (size_t)FUSED_MAX_DISPARITIES * 8;
     return w;
 }
 
@@ -131,8 +133,34 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         }
         return rc;
     }
-    set_error("filter kind %d is not implemented on the fused path yet", p->filter_kind);
-    return STEREO_EUNSUPPORTED;
+    int radius = p->median_radius;
+    double sigma = 0.0;
+    if (p->filter_kind == STEREO_FILTER_GAUSSIAN || p->filter_kind == STEREO_FILTER_BILATERAL) {
+        sigma = p->filter_kind == STEREO_FILTER_GAUSSIAN ? p->gaussian_sigma : p->bilateral_sigma;
+        radius = radius_from_sigma(sigma);
+    }
+    if (!fused_filter_supported(p->filter_kind, radius)) {
+        set_error("filter kind %d with radius %d has no fused kernel (use the layer-at-a-time path)", p->filter_kind, radius);
+        return STEREO_EUNSUPPORTED;
+    }
+    if (d_end - d_begin > FUSED_MAX_DISPARITIES) { set_error("more than %d disparities per launch", FUSED_MAX_DISPARITIES); return STEREO_EUNSUPPORTED; }
+    const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();
+    if (prof) SHP_HIP(hipEventRecord(g_prof.start[g_prof.used], s));
+    int rc = launch_fused_filter(lw, rw, cfg, H, W, p->filter_kind, radius, sigma, d_begin, d_end,
+                                 reinterpret_cast<uint32_t *>(base + L.off_mm), d_keys, s);
+    if (prof) {
+        SHP_HIP(hipEventRecord(g_prof.stop[g_prof.used], s));
+        ++g_prof.used;
+    }
+    return rc;
+}
+
+// whether compute_disparity with these parameters runs volume-free
+static bool fused_path_applies(const StereoParams *p) {
+    if (p->filter_kind == STEREO_FILTER_GUIDED) return fused_guided_supported(p->guided_radius);
+    if (p->filter_kind == STEREO_FILTER_GAUSSIAN) return fused_filter_supported(p->filter_kind, radius_from_sigma(p->gaussian_sigma));
+    if (p->filter_kind == STEREO_FILTER_BILATERAL) return fused_filter_supported(p->filter_kind, radius_from_sigma(p->bilateral_sigma));
+    return fused_filter_supported(p->filter_kind, p->median_radius);
 }
 
 // stereo.py:145-170 one layer at a time on a (D', H, W) device volume whose layer k is
@@ -361,8 +389,7 @@ int stereo_compute_disparity_host(const void *left, const void *right, int dtype
     const size_t n = (size_t)H * W;
     DevBuf keys;
     SHP_TRY(keys.alloc(n * 8));
-    const bool fused = p->filter_kind == STEREO_FILTER_GUIDED && fused_guided_supported(p->guided_radius) &&
-                       dtype != STEREO_DT_F64;
+    const bool fused = fused_path_applies(p) && dtype != STEREO_DT_F64 && d_end - d_begin <= FUSED_MAX_DISPARITIES;
     if (fused) {
         std::vector<float> lf, rf;
         const float *hl = static_cast<const float *>(left), *hr = static_cast<const float *>(right);

@@ -1,0 +1,338 @@
+// Volume-free compute_disparity for the median (uint8-quantised, "opencv"), Gaussian and
+// bilateral aggregation filters: census cost -> filter -> running WTA in one kernel
+// (census.py:187-202, filters.py:139-224,279-310, stereo.py:145-170).
+//
+// A 256-thread workgroup owns a 16 x 64 pixel tile for the whole disparity range of the launch.
+// Every thread keeps the census word, the border-mapped coordinates and the validity of "its"
+// pixels of the tile + halo in registers; per disparity it writes their costs into one of two LDS
+// cost tiles (float32, or the quantised byte for the median), the workgroup synchronises once, and
+// every thread filters four vertically adjacent output pixels from that tile and updates their
+// packed (cost, disparity) keys in registers.  Nothing but the final keys is written to HBM.
+//
+// The median needs the minimum and maximum of each unfiltered cost layer (filters.py:141-151)
+// before any pixel of the layer can be quantised: cost_minmax_kernel computes them for every
+// disparity of the launch from the census words in a first pass.
+#include <type_traits>
+
+#include "census_dev.hpp"
+
+namespace shp {
+
+constexpr int FF_TW = 64, FF_TH = 16, FF_THREADS = 256, FF_ROWS_PER_THREAD = 4;
+constexpr int FF_MAX_RADIUS = 4;
+
+struct FFArgs {
+    const void *lw, *rw;
+    CensusCfg cfg;
+    int H, W, d_begin, d_end;
+    float kern[(2 * FF_MAX_RADIUS + 1) * (2 * FF_MAX_RADIUS + 1)];  // normalised spatial weights, row-major
+    float denom;          // bilateral: 2 sigma^2
+    uint32_t *mm;         // median: [d - d_begin][2] order-preserving (min, max) of the cost layer
+    uint64_t *keys;
+};
+
+__device__ __forceinline__ int ff_reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * (n - 1) - i;
+    }
+    return i;
+}
+
+// cost of pixel (row offset ro, column gx) at disparity d; lvalid: left census centre valid
+template <typename WordT>
+__device__ __forceinline__ float ff_cost(const WordT *__restrict__ rw, const CensusCfg &cfg, WordT lword, bool lvalid,
+                                         int ro, int gx, int d) {
+    const int xr = gx - d;
+    const bool ok = lvalid && xr >= cfg.radius;
+    const WordT rword = rw[ro + (ok ? xr : gx)];
+    const float c = pair_cost<WordT>(lword, rword, cfg);
+    return ok ? c : cfg.large;
+}
+
+// ---- pass 1 (median only): min / max of every cost layer ---------------------------------------
+template <typename WordT>
+__global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restrict__ lw, const WordT *__restrict__ rw,
+                                                         CensusCfg cfg, int H, int W, int d_begin, int d_end,
+                                                         uint32_t *__restrict__ mm) {
+    constexpr int PPT = 8;  // pixels per thread: columns x0 + lane + 64 j of one row
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x0 = blockIdx.x * (64 * PPT);
+    if (y >= H) return;
+    const int R = cfg.radius;
+    const bool yvalid = y >= R && y < H - R;
+    const int ro = y * W;
+    WordT lword[PPT];
+    bool lvalid[PPT], inside[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int x = x0 + lane + 64 * j;
+        inside[j] = x < W;
+        const int xc = inside[j] ? x : W - 1;
+        lword[j] = lw[ro + xc];
+        lvalid[j] = yvalid && xc >= R && xc < W - R;
+    }
+    for (int d = d_begin; d < d_end; ++d) {
+        uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int x = min(x0 + lane + 64 * j, W - 1);
+            const uint32_t k = f32_to_ordered(ff_cost<WordT>(rw, cfg, lword[j], lvalid[j], ro, x, d));
+            if (inside[j]) { lo = min(lo, k); hi = max(hi, k); }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+        }
+        if (lane == 0) {
+            uint32_t *m = mm + 2 * (size_t)(d - d_begin);
+            if (lo < m[0]) atomicMin(&m[0], lo);
+            if (hi > m[1]) atomicMax(&m[1], hi);
+        }
+    }
+}
+
+__global__ void minmax_fill_kernel(uint32_t *mm, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { mm[2 * i] = 0xffffffffu; mm[2 * i + 1] = 0u; }
+}
+
+// ---- pass 2: cost -> filter -> WTA ------------------------------------------------------------------
+template <int FILTER, bool WORD64, int RAD>
+__global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
+    using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
+    constexpr int K = 2 * RAD + 1;
+    constexpr int LW = FF_TW + 2 * RAD, LH = FF_TH + 2 * RAD, NP = LW * LH;
+    constexpr int PT = (NP + FF_THREADS - 1) / FF_THREADS;   // halo pixels per thread
+    constexpr int NR = FF_ROWS_PER_THREAD + K - 1;           // tile rows one thread's four windows span
+    constexpr bool MEDIAN = FILTER == STEREO_FILTER_MEDIAN_U8Q;
+    __shared__ float cbuf[2][NP];
+
+    const WordT *lw = static_cast<const WordT *>(a.lw);
+    const WordT *rw = static_cast<const WordT *>(a.rw);
+    const int H = a.H, W = a.W, R = a.cfg.radius;
+    const int x0 = blockIdx.x * FF_TW, y0 = blockIdx.y * FF_TH;
+    const int tid = threadIdx.x;
+
+    // this thread's pixels of the tile + halo, with the filter's border rule applied
+    WordT lword[PT];
+    int ro[PT], gxs[PT];
+    bool lvalid[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int idx = min(tid + j * FF_THREADS, NP - 1);
+        const int ly = idx / LW, lx = idx - ly * LW;
+        int gy = y0 - RAD + ly, gx = x0 - RAD + lx;
+        if (MEDIAN) { gy = min(max(gy, 0), H - 1); gx = min(max(gx, 0), W - 1); }   // replicate (cv2.medianBlur)
+        else { gy = ff_reflect101(gy, H); gx = ff_reflect101(gx, W); }               // reflect-101
+        ro[j] = gy * W;
+        gxs[j] = gx;
+        lword[j] = lw[ro[j] + gx];
+        lvalid[j] = gy >= R && gy < H - R && gx >= R && gx < W - R;
+    }
+
+    const int lx = tid & 63, q = tid >> 6;
+    uint64_t best[FF_ROWS_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) best[j] = SHP_KEY_INIT;
+
+    for (int d = a.d_begin; d < a.d_end; ++d) {
+        float *cb = cbuf[(d - a.d_begin) & 1];
+        // quantisation of this layer (filters.py:145-151,177-180)
+        float qlo = 0.f, qscale = 0.f, qinv = 0.f;
+        bool flat = false;
+        if (MEDIAN) {
+            const uint32_t *m = a.mm + 2 * (size_t)(d - a.d_begin);
+            qlo = ordered_to_f32(m[0]);
+            const double dlo = (double)qlo, dhi = (double)ordered_to_f32(m[1]);
+            flat = dhi == dlo;
+            qscale = flat ? 0.f : (float)(255.0 / (dhi - dlo));
+            qinv = flat ? 0.f : (float)((dhi - dlo) / 255.0);
+        }
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int idx = tid + j * FF_THREADS;
+            float c = ff_cost<WordT>(rw, a.cfg, lword[j], lvalid[j], ro[j], gxs[j], d);
+            if (MEDIAN) {
+                float s = __fmul_rn(__fsub_rn(c, qlo), qscale);
+                s = fminf(fmaxf(s, 0.f), 255.f);
+                c = __uint_as_float(flat ? 0u : (uint32_t)rintf(s));
+            }
+            if (idx < NP) cb[idx] = c;
+        }
+        __syncthreads();
+
+        float outv[FF_ROWS_PER_THREAD];
+        const float *win = cb + (q * FF_ROWS_PER_THREAD) * LW + lx;
+        if (FILTER == STEREO_FILTER_GAUSSIAN) {
+#pragma unroll
+            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) outv[j] = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                float v[K];
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) v[dx] = win[rr * LW + dx];
+#pragma unroll
+                for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+                    const int dy = rr - j;
+                    if (dy >= 0 && dy < K) {
+#pragma unroll
+                        for (int dx = 0; dx < K; ++dx) outv[j] = fmaf(v[dx], a.kern[dy * K + dx], outv[j]);
+                    }
+                }
+            }
+        } else if (FILTER == STEREO_FILTER_BILATERAL) {
+            float c[FF_ROWS_PER_THREAD], wsum[FF_ROWS_PER_THREAD], vsum[FF_ROWS_PER_THREAD];
+#pragma unroll
+            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+                c[j] = win[(j + RAD) * LW + RAD];
+                wsum[j] = 0.f; vsum[j] = 0.f;
+            }
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                float v[K];
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) v[dx] = win[rr * LW + dx];
+#pragma unroll
+                for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+                    const int dy = rr - j;
+                    if (dy >= 0 && dy < K) {
+#pragma unroll
+                        for (int dx = 0; dx < K; ++dx) {
+                            // filters.py:299-304, float32, each operation rounded on its own
+                            const float diff = __fsub_rn(v[dx], c[j]);
+                            const float e = expf(__fdiv_rn(-__fmul_rn(diff, diff), a.denom));
+                            const float w = __fmul_rn(a.kern[dy * K + dx], e);
+                            wsum[j] = __fadd_rn(wsum[j], w);
+                            vsum[j] = __fadd_rn(vsum[j], __fmul_rn(v[dx], w));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) outv[j] = (wsum[j] <= 0.f) ? c[j] : __fdiv_rn(vsum[j], wsum[j]);
+        } else {
+            // Median of the K x K bytes by bisection on the value (the smallest m with
+            // count(window <= m) > K*K/2).  Three bytes share a 32-bit word in 10-bit fields; with a guard
+            // bit above each field, (m | guard) - word leaves the guard bit set exactly where byte <= m,
+            // so one subtract, one and, one popcount compare three window elements with m.
+            constexpr int WPR = (K + 2) / 3;             // words per window row
+            constexpr int PAD = WPR * 3 - K;             // empty fields per row (zero: always counted)
+            constexpr uint32_t GUARD = (1u << 8) | (1u << 18) | (1u << 28);
+            uint32_t words[NR][WPR];
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+#pragma unroll
+                for (int w = 0; w < WPR; ++w) {
+                    uint32_t acc = 0u;
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        const int dx = 3 * w + f;
+                        if (dx < K) acc |= __float_as_uint(win[rr * LW + dx]) << (10 * f);
+                    }
+                    words[rr][w] = acc;
+                }
+            }
+            constexpr int need = (K * K) / 2 + 1 + PAD * K;
+#pragma unroll
+            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+                int lo = 0, hi = 255;
+#pragma unroll
+                for (int step = 0; step < 8; ++step) {
+                    const int mid = (lo + hi) >> 1;
+                    const uint32_t mg = (uint32_t)mid * 0x00100401u + GUARD;
+                    int cnt = 0;
+#pragma unroll
+                    for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                        for (int w = 0; w < WPR; ++w) cnt += __popc((mg - words[j + dy][w]) & GUARD);
+                    if (cnt >= need) hi = mid; else lo = mid + 1;
+                }
+                outv[j] = flat ? qlo : __fadd_rn(__fmul_rn((float)lo, qinv), qlo);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+            const float v = outv[j];
+            if (v == v) {
+                const uint64_t key = make_key(v, (uint32_t)d);
+                best[j] = key < best[j] ? key : best[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+        const int gy = y0 + q * FF_ROWS_PER_THREAD + j, gx = x0 + lx;
+        if (gy < H && gx < W) a.keys[(size_t)gy * W + gx] = best[j];
+    }
+}
+
+bool fused_filter_supported(int filter_kind, int radius) {
+    return (filter_kind == STEREO_FILTER_MEDIAN_U8Q || filter_kind == STEREO_FILTER_GAUSSIAN ||
+            filter_kind == STEREO_FILTER_BILATERAL) && radius >= 1 && radius <= FF_MAX_RADIUS;
+}
+
+size_t fused_filter_minmax_bytes(int n_disp) { return (size_t)n_disp * 8; }
+
+template <int FILTER, bool WORD64, int RAD>
+static int launch_ff(const FFArgs &a, hipStream_t s) {
+    dim3 grid(ceil_div(a.W, FF_TW), ceil_div(a.H, FF_TH));
+    hipLaunchKernelGGL((fused_filter_kernel<FILTER, WORD64, RAD>), grid, dim3(FF_THREADS), 0, s, a);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+template <int FILTER, bool WORD64>
+static int launch_ff_r(const FFArgs &a, int radius, hipStream_t s) {
+    switch (radius) {
+        case 1: return launch_ff<FILTER, WORD64, 1>(a, s);
+        case 2: return launch_ff<FILTER, WORD64, 2>(a, s);
+        case 3: return launch_ff<FILTER, WORD64, 3>(a, s);
+        case 4: return launch_ff<FILTER, WORD64, 4>(a, s);
+        default: set_error("fused filter kernels support radius 1..%d", FF_MAX_RADIUS); return STEREO_EUNSUPPORTED;
+    }
+}
+template <int FILTER>
+static int launch_ff_w(const FFArgs &a, int radius, hipStream_t s) {
+    return a.cfg.word64 ? launch_ff_r<FILTER, true>(a, radius, s) : launch_ff_r<FILTER, false>(a, radius, s);
+}
+
+// d_mm: scratch of fused_filter_minmax_bytes(d_end - d_begin) bytes (median only)
+int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg, int H, int W, int filter_kind,
+                        int radius, double sigma, int d_begin, int d_end, uint32_t *d_mm, uint64_t *d_keys,
+                        hipStream_t s) {
+    if (H <= 0 || W <= 0) return STEREO_OK;
+    if (!fused_filter_supported(filter_kind, radius)) { set_error("unsupported fused filter"); return STEREO_EUNSUPPORTED; }
+    if ((size_t)H * W > 0x7fffffffu) { set_error("image too large for the fused filter kernels"); return STEREO_EUNSUPPORTED; }
+    if (d_begin >= d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
+    FFArgs a;
+    memset(&a, 0, sizeof(a));
+    a.lw = d_lw; a.rw = d_rw; a.cfg = cfg; a.H = H; a.W = W; a.d_begin = d_begin; a.d_end = d_end;
+    a.mm = d_mm; a.keys = d_keys;
+    if (filter_kind != STEREO_FILTER_MEDIAN_U8Q) {
+        gaussian_kernel_host(radius, sigma, a.kern);
+        a.denom = (float)(2.0 * (double)(sigma * sigma));
+    }
+    switch (filter_kind) {
+        case STEREO_FILTER_MEDIAN_U8Q: {
+            const int nd = d_end - d_begin;
+            hipLaunchKernelGGL(minmax_fill_kernel, dim3(ceil_div(nd, 256)), dim3(256), 0, s, d_mm, nd);
+            SHP_LAUNCH_CHECK();
+            dim3 grid(ceil_div(W, 64 * 8), ceil_div(H, 4));
+            if (cfg.word64)
+                hipLaunchKernelGGL(cost_minmax_kernel<uint64_t>, grid, dim3(256), 0, s, static_cast<const uint64_t *>(d_lw),
+                                   static_cast<const uint64_t *>(d_rw), cfg, H, W, d_begin, d_end, d_mm);
+            else
+                hipLaunchKernelGGL(cost_minmax_kernel<uint32_t>, grid, dim3(256), 0, s, static_cast<const uint32_t *>(d_lw),
+                                   static_cast<const uint32_t *>(d_rw), cfg, H, W, d_begin, d_end, d_mm);
+            SHP_LAUNCH_CHECK();
+            return launch_ff_w<STEREO_FILTER_MEDIAN_U8Q>(a, radius, s);
+        }
+        case STEREO_FILTER_GAUSSIAN: return launch_ff_w<STEREO_FILTER_GAUSSIAN>(a, radius, s);
+        default: return launch_ff_w<STEREO_FILTER_BILATERAL>(a, radius, s);
+    }
+}
+
+}  // namespace shp
