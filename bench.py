@@ -34,7 +34,11 @@ WORKLOADS = {
                    "Motorcycle-perfect shaped synthetic pair 2964x2000, dmax=270, wct_radius=4, guided r=3 eps=0.0154"),
     "4k": (2160, 3840, 512, 4, 3840,
            "synthetic 3840x2160 pair, dmax=512, wct_radius=4, guided r=3 eps=0.0154"),
+    # BASELINE config 5: census radius 8 with the other aggregation filters (chosen with --filter)
+    "8k": (4320, 7680, 256, 8, 7680, "synthetic 7680x4320 pair, dmax=256, wct_radius=8"),
 }
+FILTERS = {"guided": "FILTER_GUIDED", "median": "FILTER_MEDIAN_U8Q", "gaussian": "FILTER_GAUSSIAN",
+           "bilateral": "FILTER_BILATERAL"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
 # per-launch counter averages of a `rocprofv3 --pmc` run of this same command (tools/pmc_passes.sh)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "pair_pmc_per_launch.json")
@@ -64,6 +68,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="motorcycle")
+    ap.add_argument("--filter", choices=sorted(FILTERS), default="guided",
+                    help="aggregation filter (median = the reference's default uint8-quantised method, radius 3; "
+                         "gaussian / bilateral sigma 1)")
     ap.add_argument("--cpu-rows", type=int, default=160, help="rows of the workload the CPU baseline is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -123,7 +130,9 @@ def main() -> None:
     left_np, right_np, _ = synth_pair_gray(H, W, D, seed)
     left = torch.from_numpy(left_np).to(dev)
     right = torch.from_numpy(right_np).to(dev)
-    params = _native.StereoParams(wct_radius=r_c, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=3,
+    if args.filter != "guided":
+        desc += f", filter={args.filter}"
+    params = _native.StereoParams(wct_radius=r_c, base_weight=8.0, filter_kind=getattr(_native, FILTERS[args.filter]), guided_radius=3,
                                   guided_eps=0.0154, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
     ws_bytes = ctypes.c_size_t(0)
     _native.check(lib.stereo_fused_workspace_bytes(H, W, params, ctypes.byref(ws_bytes)))
@@ -193,7 +202,7 @@ def main() -> None:
         alg_bytes = H * W * (8 * d_local + 16)  # DSI-equivalent bytes of one fused launch
         achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
         out = {
-            "metric": "MDE/s (10^6 pixel-disparity evals/s), fused WCT+guided+WTA",
+            "metric": f"MDE/s (10^6 pixel-disparity evals/s), fused WCT+{args.filter}+WTA",
             "value": round(evals * args.steps / elapsed / 1e6, 1),
             "unit": "MDE/s",
             "n_gpus": world,
@@ -211,8 +220,8 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_hbm_traffic(args.workload) if world == 1 else None,
-                "kernel": DOMINANT_KERNEL, "kernel_ms": round(kernel_avg_ms, 4),
+                "traffic": measured_hbm_traffic(args.workload) if world == 1 and args.filter == "guided" else None,
+                "kernel": DOMINANT_KERNEL if args.filter == "guided" else "fused_filter_kernel", "kernel_ms": round(kernel_avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "compulsory_frac": round(H * W * 16 / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 if kernel_avg_ms > 0 else None,
@@ -223,7 +232,7 @@ def main() -> None:
                         "not by HBM",
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.filter == "guided" and r_c == 4:
             out["cpu_baseline"] = cpu_baseline(left_np, right_np, D, args.cpu_rows)
         print(json.dumps(out), flush=True)
     if world > 1:

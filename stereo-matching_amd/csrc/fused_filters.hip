@@ -26,7 +26,7 @@ struct FFArgs {
     CensusCfg cfg;
     int H, W, d_begin, d_end;
     float kern[(2 * FF_MAX_RADIUS + 1) * (2 * FF_MAX_RADIUS + 1)];  // normalised spatial weights, row-major
-    float denom;          // bilateral: 2 sigma^2
+    float denom;          // bilateral: -log2(e) / (2 sigma^2)
     uint32_t *mm;         // median: [d - d_begin][2] order-preserving (min, max) of the cost layer
     uint64_t *keys;
 };
@@ -100,6 +100,69 @@ __global__ void minmax_fill_kernel(uint32_t *mm, int n) {
     if (i < n) { mm[2 * i] = 0xffffffffu; mm[2 * i + 1] = 0u; }
 }
 
+// Medians of four vertically adjacent K x K windows of bytes (stored one per float slot, as integer
+// bits) by bisection on the value: the median is the smallest m with count(window <= m) > K*K/2.
+// NPW = 32 / FB window elements share a 32-bit word in FB-bit fields holding (byte - tlo); with a
+// guard bit on top of each field, (m | guards) - word leaves the guard bit set exactly where the
+// element is <= m, so one subtract, one and, one popcount compare NPW elements with m.
+template <int K, int FB, int LW>
+__device__ __forceinline__ void median_bisect(const float *win, int tlo, int thi, int *med) {
+    constexpr int NR = FF_ROWS_PER_THREAD + K - 1;
+    constexpr int NPW = 32 / FB;
+    constexpr int FULL = K / NPW;                // full words per window row
+    constexpr int REM = K - NPW * FULL;          // elements of a row left over
+    constexpr int NREST = (REM * K + NPW - 1) / NPW;
+    constexpr int PAD = NREST * NPW - REM * K;   // empty fields (zero: always counted)
+    uint32_t guard = 0u, ones = 0u;
+#pragma unroll
+    for (int f = 0; f < NPW; ++f) { guard |= 1u << (FB * f + FB - 1); ones |= 1u << (FB * f); }
+    uint32_t words[NR][FULL > 0 ? FULL : 1];
+    uint32_t rest[NR][REM > 0 ? REM : 1];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+#pragma unroll
+        for (int w = 0; w < FULL; ++w) {
+            uint32_t acc = 0u;
+#pragma unroll
+            for (int f = 0; f < NPW; ++f) acc |= (__float_as_uint(win[rr * LW + NPW * w + f]) - (uint32_t)tlo) << (FB * f);
+            words[rr][w] = acc;
+        }
+#pragma unroll
+        for (int f = 0; f < REM; ++f) rest[rr][f] = __float_as_uint(win[rr * LW + NPW * FULL + f]) - (uint32_t)tlo;
+    }
+    int steps = 0;
+    while ((1 << steps) <= thi - tlo) ++steps;
+#pragma unroll
+    for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+        uint32_t rw[NREST > 0 ? NREST : 1];
+#pragma unroll
+        for (int w = 0; w < NREST; ++w) {
+            uint32_t acc = 0u;
+#pragma unroll
+            for (int f = 0; f < NPW; ++f) {
+                const int e = NPW * w + f;
+                if (e < REM * K) acc |= rest[j + e / (REM > 0 ? REM : 1)][e % (REM > 0 ? REM : 1)] << (FB * f);
+            }
+            rw[w] = acc;
+        }
+        constexpr int need = (K * K) / 2 + 1 + PAD;
+        int lo = 0, hi = thi - tlo;
+        for (int step = 0; step < steps; ++step) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t mg = (uint32_t)mid * ones + guard;
+            int cnt = 0;
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                for (int w = 0; w < FULL; ++w) cnt += __popc((mg - words[j + dy][w]) & guard);
+#pragma unroll
+            for (int w = 0; w < NREST; ++w) cnt += __popc((mg - rw[w]) & guard);
+            if (cnt >= need) hi = mid; else lo = mid + 1;
+        }
+        med[j] = lo + tlo;
+    }
+}
+
 // ---- pass 2: cost -> filter -> WTA ------------------------------------------------------------------
 template <int FILTER, bool WORD64, int RAD>
 __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
@@ -110,6 +173,9 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
     constexpr int NR = FF_ROWS_PER_THREAD + K - 1;           // tile rows one thread's four windows span
     constexpr bool MEDIAN = FILTER == STEREO_FILTER_MEDIAN_U8Q;
     __shared__ float cbuf[2][NP];
+    // median: min / max byte of the cost tiles of disparities d, d + 1, d + 2 (slot = index mod 3); a slot is
+    // reset two iterations before it is used, after the barrier that ends its last readers
+    __shared__ uint32_t trange_buf[3][2];
 
     const WordT *lw = static_cast<const WordT *>(a.lw);
     const WordT *rw = static_cast<const WordT *>(a.rw);
@@ -139,6 +205,10 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
 #pragma unroll
     for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) best[j] = SHP_KEY_INIT;
 
+    if (MEDIAN) {
+        if (tid < 3) { trange_buf[tid][0] = 255u; trange_buf[tid][1] = 0u; }
+        __syncthreads();
+    }
     for (int d = a.d_begin; d < a.d_end; ++d) {
         float *cb = cbuf[(d - a.d_begin) & 1];
         // quantisation of this layer (filters.py:145-151,177-180)
@@ -152,6 +222,8 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             qscale = flat ? 0.f : (float)(255.0 / (dhi - dlo));
             qinv = flat ? 0.f : (float)((dhi - dlo) / 255.0);
         }
+        uint32_t *trange = trange_buf[(d - a.d_begin) % 3];
+        uint32_t mylo = 255u, myhi = 0u;
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const int idx = tid + j * FF_THREADS;
@@ -159,11 +231,31 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             if (MEDIAN) {
                 float s = __fmul_rn(__fsub_rn(c, qlo), qscale);
                 s = fminf(fmaxf(s, 0.f), 255.f);
-                c = __uint_as_float(flat ? 0u : (uint32_t)rintf(s));
+                const uint32_t b = flat ? 0u : (uint32_t)rintf(s);
+                mylo = min(mylo, b); myhi = max(myhi, b);   // (a thread's surplus slot repeats a tile pixel)
+                c = __uint_as_float(b);
             }
             if (idx < NP) cb[idx] = c;
         }
+        if (MEDIAN) {
+            // one LDS atomic pair per wavefront: (255 - min) and max travel through the lanes in one word
+            uint32_t nlo = 255u - mylo;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)((nlo << 8) | myhi), off, 64);
+                nlo = max(nlo, other >> 8);
+                myhi = max(myhi, other & 255u);
+            }
+            if ((tid & 63) == 0) {
+                atomicMin(&trange[0], 255u - nlo);
+                atomicMax(&trange[1], myhi);
+            }
+        }
         __syncthreads();
+        if (MEDIAN && tid == 0) {
+            uint32_t *later = trange_buf[(d - a.d_begin + 2) % 3];
+            later[0] = 255u; later[1] = 0u;
+        }
 
         float outv[FF_ROWS_PER_THREAD];
         const float *win = cb + (q * FF_ROWS_PER_THREAD) * LW + lx;
@@ -185,6 +277,9 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                 }
             }
         } else if (FILTER == STEREO_FILTER_BILATERAL) {
+            // w = spatial * exp(-(v - c)^2 / (2 sigma^2))  (filters.py:299-304) evaluated as one hardware
+            // exp2 per window element: exp2((v - c)^2 * (-log2(e) / (2 sigma^2)) + log2(spatial)).  The
+            // weights agree with the reference's to a few float32 ulps, the filtered cost to ~1e-6.
             float c[FF_ROWS_PER_THREAD], wsum[FF_ROWS_PER_THREAD], vsum[FF_ROWS_PER_THREAD];
 #pragma unroll
             for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
@@ -202,12 +297,10 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                     if (dy >= 0 && dy < K) {
 #pragma unroll
                         for (int dx = 0; dx < K; ++dx) {
-                            // filters.py:299-304, float32, each operation rounded on its own
-                            const float diff = __fsub_rn(v[dx], c[j]);
-                            const float e = expf(__fdiv_rn(-__fmul_rn(diff, diff), a.denom));
-                            const float w = __fmul_rn(a.kern[dy * K + dx], e);
-                            wsum[j] = __fadd_rn(wsum[j], w);
-                            vsum[j] = __fadd_rn(vsum[j], __fmul_rn(v[dx], w));
+                            const float diff = v[dx] - c[j];
+                            const float w = __builtin_amdgcn_exp2f(fmaf(diff * diff, a.denom, a.kern[dy * K + dx]));
+                            wsum[j] += w;
+                            vsum[j] = fmaf(v[dx], w, vsum[j]);
                         }
                     }
                 }
@@ -215,44 +308,15 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
 #pragma unroll
             for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) outv[j] = (wsum[j] <= 0.f) ? c[j] : __fdiv_rn(vsum[j], wsum[j]);
         } else {
-            // Median of the K x K bytes by bisection on the value (the smallest m with
-            // count(window <= m) > K*K/2).  Three bytes share a 32-bit word in 10-bit fields; with a guard
-            // bit above each field, (m | guard) - word leaves the guard bit set exactly where byte <= m,
-            // so one subtract, one and, one popcount compare three window elements with m.
-            constexpr int WPR = (K + 2) / 3;             // words per window row
-            constexpr int PAD = WPR * 3 - K;             // empty fields per row (zero: always counted)
-            constexpr uint32_t GUARD = (1u << 8) | (1u << 18) | (1u << 28);
-            uint32_t words[NR][WPR];
+            // the bytes of this tile (halo included) lie in [tlo, thi]: so do all its medians.  Cost
+            // layers mostly hold a narrow band of levels, and then five values fit a word (6-bit fields).
+            const int tlo = (int)trange[0], thi = (int)trange[1];
+            int med[FF_ROWS_PER_THREAD];
+            if (thi - tlo < 32) median_bisect<K, 6, LW>(win, tlo, thi, med);
+            else median_bisect<K, 10, LW>(win, tlo, thi, med);
 #pragma unroll
-            for (int rr = 0; rr < NR; ++rr) {
-#pragma unroll
-                for (int w = 0; w < WPR; ++w) {
-                    uint32_t acc = 0u;
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) {
-                        const int dx = 3 * w + f;
-                        if (dx < K) acc |= __float_as_uint(win[rr * LW + dx]) << (10 * f);
-                    }
-                    words[rr][w] = acc;
-                }
-            }
-            constexpr int need = (K * K) / 2 + 1 + PAD * K;
-#pragma unroll
-            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
-                int lo = 0, hi = 255;
-#pragma unroll
-                for (int step = 0; step < 8; ++step) {
-                    const int mid = (lo + hi) >> 1;
-                    const uint32_t mg = (uint32_t)mid * 0x00100401u + GUARD;
-                    int cnt = 0;
-#pragma unroll
-                    for (int dy = 0; dy < K; ++dy)
-#pragma unroll
-                        for (int w = 0; w < WPR; ++w) cnt += __popc((mg - words[j + dy][w]) & GUARD);
-                    if (cnt >= need) hi = mid; else lo = mid + 1;
-                }
-                outv[j] = flat ? qlo : __fadd_rn(__fmul_rn((float)lo, qinv), qlo);
-            }
+            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j)
+                outv[j] = flat ? qlo : __fadd_rn(__fmul_rn((float)med[j], qinv), qlo);
         }
 #pragma unroll
         for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
@@ -313,7 +377,12 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
     a.mm = d_mm; a.keys = d_keys;
     if (filter_kind != STEREO_FILTER_MEDIAN_U8Q) {
         gaussian_kernel_host(radius, sigma, a.kern);
-        a.denom = (float)(2.0 * (double)(sigma * sigma));
+        if (filter_kind == STEREO_FILTER_BILATERAL) {
+            const int kk = (2 * radius + 1) * (2 * radius + 1);
+            for (int i = 0; i < kk; ++i) a.kern[i] = (float)std::log2((double)a.kern[i]);
+            const double denom = (double)(float)(2.0 * (sigma * sigma));   // the reference's float32 denominator
+            a.denom = (float)(-1.4426950408889634 / denom);
+        }
     }
     switch (filter_kind) {
         case STEREO_FILTER_MEDIAN_U8Q: {
