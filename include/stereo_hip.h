@@ -132,7 +132,10 @@ int stereo_fused_workspace_bytes(int height, int width, const StereoParams *para
 /* Fused compute_disparity over d in [d_begin, d_end) on float32 device images.  Writes one
  * packed key per pixel: (order-preserving uint32 image of the float32 min cost) << 32 | d, so
  * that an unsigned 64-bit MIN over keys of different disparity shards is the reference's
- * "lowest cost, ties to the lowest disparity" rule (stereo.py:167-170). */
+ * "lowest cost, ties to the lowest disparity" rule (stereo.py:167-170).
+ * Covers the guided filter (radius 1..4), the uint8-quantised median (radius 1..4) and the
+ * Gaussian / bilateral filters (ceil(3 sigma) <= 4); other parameters return STEREO_EUNSUPPORTED
+ * (the host entry point falls back to the layer-at-a-time path for them). */
 int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int height, int width, int dmax,
                                  const StereoParams *params, int d_begin, int d_end, void *d_workspace,
                                  size_t workspace_bytes, uint64_t *d_keys, void *stream);
