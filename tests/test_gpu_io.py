@@ -168,3 +168,22 @@ def test_cli_single_scene_and_batch(oracle, tmp_path, capsys):
 
     with pytest.raises(ValueError):
         stereo.main(["--dataset", "Alpha-perfect", "--all-datasets"], dataset_root=str(root), result_root=str(result))
+
+
+def test_eval_npz_tool(gold, tmp_path, capsys):
+    from PIL import Image
+
+    import eval_npz
+    import stereo_io
+
+    npz, gt, mask, out = (str(tmp_path / n) for n in ("d.npz", "gt.pfm", "m.pgm", "metrics.json"))
+    stereo_io.save_disparity_npz(npz, gold["metrics_disp"], gold["metrics_gt"].astype(np.float32))
+    stereo_io.write_pfm(gt, gold["metrics_gt"])
+    Image.fromarray(gold["metrics_mask"].astype(np.uint8) * 255).save(mask)
+    eval_npz.main(["--npz", npz, "--gt", gt, "--gt_mask", mask, "--output_json", out])   # default threshold 1.0
+    want = gold["metrics_thr1.0"]
+    got = json.loads(open(out).read())
+    assert got["pbm"] == want[0] and abs(got["rms"] - want[1]) <= 1e-6 * want[1] and got["bad_threshold"] == 1.0
+    assert "PBM:" in capsys.readouterr().out
+    with pytest.raises(ValueError):
+        eval_npz.main(["--npz", npz, "--gt", gt, "--gt_mask", mask, "--key", "nope"])

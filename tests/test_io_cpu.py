@@ -299,3 +299,17 @@ def test_progress_printers(capsys):
     stereo._print_metrics({"pbm": 12.34567, "rms": 1.5, "bad_threshold": 2.0, "valid_pixel_count": 100.0})
     out = capsys.readouterr().out
     assert "PBM: 12.3457%" in out and "RMS: 1.5000" in out and "Valid Pixel Count: 100" in out
+
+
+def test_convert_tool(tmp_path):
+    import convert
+
+    d = np.arange(20, dtype=np.float32).reshape(4, 5)
+    npz, pfm, back = str(tmp_path / "a.npz"), str(tmp_path / "a.pfm"), str(tmp_path / "b.npz")
+    stereo_io.save_npz(npz, {"disparity": d})
+    convert.main(["--input", npz, "--output", pfm, "--mode", "npz2pfm"])
+    np.testing.assert_array_equal(stereo_io.read_pfm(pfm), d)
+    convert.main(["--input", pfm, "--output", back, "--mode", "pfm2npz", "--key", "gt"])
+    np.testing.assert_array_equal(stereo_io.load_npz(back)["gt"], d)
+    with pytest.raises(SystemExit):
+        convert.main(["--input", npz, "--output", pfm, "--mode", "other"])
