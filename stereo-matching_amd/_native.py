@@ -12,7 +12,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstereo_hip.so")
+# STEREO_HIP_LIB selects another build of the same library (A/B timing of compiler flags)
+LIB_PATH = os.environ.get("STEREO_HIP_LIB") or os.path.join(_HERE, "libstereo_hip.so")
 
 OK, EINVAL, EUNSUPPORTED, EHIP, ENOMEM, ENONFINITE = 0, -1, -2, -3, -4, -5
 DT_F32, DT_F64, DT_U8, DT_U16 = 0, 1, 2, 3

@@ -58,6 +58,8 @@ static int check_params(const StereoParams *p) {
 static int check_image_dims(int H, int W) {
     if (H <= 0 || W <= 0) { set_error("image must be non-empty, got %d x %d", H, W); return STEREO_EINVAL; }
     if (H > 65535) { set_error("image height %d exceeds 65535", H); return STEREO_EUNSUPPORTED; }
+    // the kernels address census words with 32-bit byte offsets (8 bytes per pixel at census radius > 4)
+    if ((size_t)H * (size_t)W > ((size_t)1 << 27)) { set_error("image of %d x %d pixels exceeds 2^27 pixels", H, W); return STEREO_EUNSUPPORTED; }
     return STEREO_OK;
 }
 
