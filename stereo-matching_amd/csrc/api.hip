@@ -105,8 +105,7 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
     void *lw = base + L.off_lw, *rw = base + L.off_rw;
     double *mean = reinterpret_cast<double *>(base + L.off_mean);
     double *invden = reinterpret_cast<double *>(base + L.off_invden);
-    SHP_TRY(launch_census_pack(d_left, STEREO_DT_F32, H, W, p->wct_radius, lw, s));
-    SHP_TRY(launch_census_pack(d_right, STEREO_DT_F32, H, W, p->wct_radius, rw, s));
+    SHP_TRY(launch_census_pack_pair(d_left, d_right, STEREO_DT_F32, H, W, p->wct_radius, lw, rw, s));
     if (p->filter_kind == STEREO_FILTER_GUIDED) {
         if (!fused_guided_supported(p->guided_radius)) {
             set_error("fused guided path supports radius 1..4, got %d", p->guided_radius);
@@ -307,8 +306,7 @@ int stereo_wct_cost_volume_host(const void *left, const void *right, int dtype, 
     SHP_TRY(dsi.alloc(n * (size_t)dmax * sizeof(float)));
     SHP_HIP(hipMemcpy(dl.p, left, img_bytes, hipMemcpyHostToDevice));
     SHP_HIP(hipMemcpy(dr.p, right, img_bytes, hipMemcpyHostToDevice));
-    SHP_TRY(launch_census_pack(dl.p, dtype, H, W, radius, lw.p, nullptr));
-    SHP_TRY(launch_census_pack(dr.p, dtype, H, W, radius, rw.p, nullptr));
+    SHP_TRY(launch_census_pack_pair(dl.p, dr.p, dtype, H, W, radius, lw.p, rw.p, nullptr));
     SHP_TRY(launch_dsi(lw.p, rw.p, H, W, dmax, cfg, dsi.as<float>(), nullptr));
     SHP_HIP(hipMemcpy(out_dsi, dsi.p, n * (size_t)dmax * sizeof(float), hipMemcpyDeviceToHost));
     return STEREO_OK;
@@ -418,8 +416,7 @@ int stereo_compute_disparity_host(const void *left, const void *right, int dtype
     SHP_TRY(layers.alloc(n * (size_t)(d_end - d_begin) * 4));
     SHP_HIP(hipMemcpy(dl.p, left, img_bytes, hipMemcpyHostToDevice));
     SHP_HIP(hipMemcpy(dr.p, right, img_bytes, hipMemcpyHostToDevice));
-    SHP_TRY(launch_census_pack(dl.p, dtype, H, W, p->wct_radius, lw.p, nullptr));
-    SHP_TRY(launch_census_pack(dr.p, dtype, H, W, p->wct_radius, rw.p, nullptr));
+    SHP_TRY(launch_census_pack_pair(dl.p, dr.p, dtype, H, W, p->wct_radius, lw.p, rw.p, nullptr));
     SHP_TRY(launch_dsi_layers(lw.p, rw.p, H, W, d_begin, d_end, cfg, layers.as<float>(), nullptr));
     const void *g = dl.p;
     int gdt = dtype;

@@ -75,67 +75,97 @@ int make_census_cfg(int radius, double base_weight, CensusCfg *cfg) {
 constexpr int CP_TW = 64;  // tile width  (one wavefront per row)
 constexpr int CP_TH = 16;  // tile height
 
-template <typename T, typename WordT>
-__global__ __launch_bounds__(256) void census_pack_kernel(const T *__restrict__ img, int H, int W, int R,
-                                                          WordT *__restrict__ words) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *tile = reinterpret_cast<T *>(smem_raw);
-    const int LW = CP_TW + 2 * R, LH = CP_TH + 2 * R;
+// lowest value of the image type: a neighbour outside the image compares "not greater" (census.py:140-146)
+template <typename T> __device__ __forceinline__ T census_lowest();
+template <> __device__ __forceinline__ float census_lowest<float>() { return -__builtin_inff(); }
+template <> __device__ __forceinline__ double census_lowest<double>() { return -__builtin_inf(); }
+template <> __device__ __forceinline__ uint8_t census_lowest<uint8_t>() { return 0; }
+
+// One packed census word per pixel.  blockIdx.z selects the image, so the left and the right image
+// of a pair are packed by one launch.  The tile and its halo are staged in LDS with out-of-image
+// cells set to the lowest value; bits are shifted in from the most significant one down (direction 7
+// ring 1 first), so that every neighbour costs one compare and one shift-or.
+template <typename T, typename WordT, int R>
+__global__ __launch_bounds__(256) void census_pack_kernel(const T *__restrict__ img0, const T *__restrict__ img1,
+                                                          int H, int W, WordT *__restrict__ words0,
+                                                          WordT *__restrict__ words1) {
+    constexpr int LW = CP_TW + 2 * R, LH = CP_TH + 2 * R;
+    constexpr int FB = (sizeof(WordT) == 8) ? 8 : 4;
+    __shared__ T tile[LH * LW];
+    const T *__restrict__ img = blockIdx.z ? img1 : img0;
+    WordT *__restrict__ words = blockIdx.z ? words1 : words0;
     const int x0 = blockIdx.x * CP_TW, y0 = blockIdx.y * CP_TH;
-    // stage the tile and its halo; out-of-image cells are never compared (masked below)
-    for (int i = threadIdx.x; i < LW * LH; i += blockDim.x) {
-        int ly = i / LW, lx = i - ly * LW;
-        int gy = y0 - R + ly, gx = x0 - R + lx;
-        T v = T(0);
+    for (int i = threadIdx.x; i < LW * LH; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = y0 - R + ly, gx = x0 - R + lx;
+        T v = census_lowest<T>();
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img[(size_t)gy * W + gx];
         tile[i] = v;
     }
     __syncthreads();
-    const int FB = (sizeof(WordT) == 8) ? 8 : 4;
-    const int dys[8] = {1, -1, 0, 0, 1, 1, -1, -1};
-    const int dxs[8] = {0, 0, 1, -1, 1, -1, 1, -1};
+    constexpr int dys[8] = {1, -1, 0, 0, 1, 1, -1, -1};
+    constexpr int dxs[8] = {0, 0, 1, -1, 1, -1, 1, -1};
     const int lx = threadIdx.x & 63;
-    for (int ly = threadIdx.x >> 6; ly < CP_TH; ly += 4) {
-        int gy = y0 + ly, gx = x0 + lx;
-        if (gy >= H || gx >= W) continue;
-        T c = tile[(ly + R) * LW + (lx + R)];
+#pragma unroll
+    for (int i = 0; i < CP_TH / 4; ++i) {
+        const int ly = (threadIdx.x >> 6) + 4 * i;
+        const int gy = y0 + ly, gx = x0 + lx;
+        const T *c0 = tile + (ly + R) * LW + (lx + R);
+        const T c = *c0;
         WordT word = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            for (int r = 1; r <= R; ++r) {
-                int ny = gy + dys[k] * r, nx = gx + dxs[k] * r;
-                bool inside = (ny >= 0) & (ny < H) & (nx >= 0) & (nx < W);
-                T v = tile[(ly + R + dys[k] * r) * LW + (lx + R + dxs[k] * r)];
-                WordT bit = (inside && (v > c)) ? WordT(1) : WordT(0);
-                word |= bit << (FB * k + (FB - r));
-            }
+        for (int k = 7; k >= 0; --k) {
+#pragma unroll
+            for (int r = 1; r <= R; ++r) word = (word << 1) | (WordT)(c0[dys[k] * r * LW + dxs[k] * r] > c ? 1 : 0);
+            if (FB > R) word <<= (k > 0 ? FB - R : 0);
         }
-        words[(size_t)gy * W + gx] = word;
+        // ring r of direction k sits at bit FB * k + (FB - r)
+        if (FB > R) word <<= (FB - R);
+        if (gy < H && gx < W) words[(size_t)gy * W + gx] = word;
     }
 }
 
-template <typename T>
-static int launch_census_pack_t(const T *img, int H, int W, int R, void *words, hipStream_t s) {
-    dim3 grid(ceil_div(W, CP_TW), ceil_div(H, CP_TH));
-    size_t smem = (size_t)(CP_TW + 2 * R) * (CP_TH + 2 * R) * sizeof(T);
-    if (R <= 4)
-        hipLaunchKernelGGL((census_pack_kernel<T, uint32_t>), grid, dim3(256), smem, s, img, H, W, R,
-                           static_cast<uint32_t *>(words));
-    else
-        hipLaunchKernelGGL((census_pack_kernel<T, uint64_t>), grid, dim3(256), smem, s, img, H, W, R,
-                           static_cast<uint64_t *>(words));
+template <typename T, typename WordT>
+static int launch_census_pack_r(const T *img0, const T *img1, int H, int W, int R, WordT *w0, WordT *w1, hipStream_t s) {
+    dim3 grid(ceil_div(W, CP_TW), ceil_div(H, CP_TH), img1 ? 2 : 1);
+#define SHP_CP_CASE(RR) \
+    case RR: hipLaunchKernelGGL((census_pack_kernel<T, WordT, RR>), grid, dim3(256), 0, s, img0, img1, H, W, w0, w1); break;
+    switch (R) {
+        SHP_CP_CASE(1) SHP_CP_CASE(2) SHP_CP_CASE(3) SHP_CP_CASE(4) SHP_CP_CASE(5) SHP_CP_CASE(6) SHP_CP_CASE(7) SHP_CP_CASE(8)
+        default: set_error("census radius %d is outside 1..8", R); return STEREO_EUNSUPPORTED;
+    }
+#undef SHP_CP_CASE
     SHP_LAUNCH_CHECK();
     return STEREO_OK;
 }
 
-int launch_census_pack(const void *d_img, int dtype, int H, int W, int radius, void *d_words, hipStream_t s) {
+template <typename T>
+static int launch_census_pack_t(const T *img0, const T *img1, int H, int W, int R, void *w0, void *w1, hipStream_t s) {
+    if (R <= 4)
+        return launch_census_pack_r<T, uint32_t>(img0, img1, H, W, R, static_cast<uint32_t *>(w0), static_cast<uint32_t *>(w1), s);
+    return launch_census_pack_r<T, uint64_t>(img0, img1, H, W, R, static_cast<uint64_t *>(w0), static_cast<uint64_t *>(w1), s);
+}
+
+// d_img1 / d_words1 may be null (one image)
+int launch_census_pack_pair(const void *d_img0, const void *d_img1, int dtype, int H, int W, int radius, void *d_words0,
+                            void *d_words1, hipStream_t s) {
     if (H <= 0 || W <= 0) return STEREO_OK;
     switch (dtype) {
-        case STEREO_DT_F32: return launch_census_pack_t(static_cast<const float *>(d_img), H, W, radius, d_words, s);
-        case STEREO_DT_F64: return launch_census_pack_t(static_cast<const double *>(d_img), H, W, radius, d_words, s);
-        case STEREO_DT_U8: return launch_census_pack_t(static_cast<const uint8_t *>(d_img), H, W, radius, d_words, s);
+        case STEREO_DT_F32:
+            return launch_census_pack_t(static_cast<const float *>(d_img0), static_cast<const float *>(d_img1), H, W, radius,
+                                        d_words0, d_words1, s);
+        case STEREO_DT_F64:
+            return launch_census_pack_t(static_cast<const double *>(d_img0), static_cast<const double *>(d_img1), H, W, radius,
+                                        d_words0, d_words1, s);
+        case STEREO_DT_U8:
+            return launch_census_pack_t(static_cast<const uint8_t *>(d_img0), static_cast<const uint8_t *>(d_img1), H, W,
+                                        radius, d_words0, d_words1, s);
         default: set_error("unsupported image dtype %d", dtype); return STEREO_EINVAL;
     }
+}
+
+int launch_census_pack(const void *d_img, int dtype, int H, int W, int radius, void *d_words, hipStream_t s) {
+    return launch_census_pack_pair(d_img, nullptr, dtype, H, W, radius, d_words, nullptr, s);
 }
 
 // ---- materialised cost volume, D innermost (census.py:250) -----------------------------------

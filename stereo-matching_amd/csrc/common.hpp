@@ -105,6 +105,8 @@ int make_census_cfg(int radius, double base_weight, CensusCfg *cfg);
 
 // ---- kernel launchers (device pointers, stream) ---------------------------------------------
 int launch_census_pack(const void *d_img, int dtype, int H, int W, int radius, void *d_words, hipStream_t s);
+int launch_census_pack_pair(const void *d_img0, const void *d_img1, int dtype, int H, int W, int radius, void *d_words0,
+                            void *d_words1, hipStream_t s);
 int launch_dsi(const void *d_lw, const void *d_rw, int H, int W, int dmax, const CensusCfg &cfg, float *d_dsi,
                hipStream_t s);
 int launch_unpack_keys(const uint64_t *keys, size_t n, int32_t *disp, float *cost, hipStream_t s);
