@@ -145,11 +145,10 @@ def main() -> None:
     d_begin, d_end = sharding.shard_range(D, world, rank)
     if world > 1:
         recv = torch.empty(n_pad, dtype=torch.int64, device=dev)
-        disp_part = torch.empty(chunk, dtype=torch.int32, device=dev)
-        cost_part = torch.empty(chunk, dtype=torch.float32, device=dev)
-    else:
-        disp = torch.empty(n, dtype=torch.int32, device=dev)
-        cost = torch.empty(n, dtype=torch.float32, device=dev)
+        frame_keys = torch.empty(n_pad, dtype=torch.int64, device=dev) if rank == 0 else None
+    full = n_pad if (world > 1 and rank == 0) else n
+    disp = torch.empty(full, dtype=torch.int32, device=dev)
+    cost = torch.empty(full, dtype=torch.float32, device=dev)
 
     def step() -> None:
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -160,14 +159,15 @@ def main() -> None:
             _native.check(lib.stereo_unpack_keys_dev(keys.data_ptr(), n, disp.data_ptr(), cost.data_ptr(), stream))
             return
         # every rank sends pixel slice j of its shard's keys to rank j over its direct xGMI link,
-        # min-merges the N slices it receives, unpacks them and hands its slice to rank 0
+        # min-merges the N slices it receives and hands its merged slice to rank 0
         def merge(dst, src):
             _native.check(lib.stereo_merge_keys_dev(dst.data_ptr(), src.data_ptr(), dst.numel(), stream))
 
         merged = sharding.exchange_and_merge(keys, world, merge, recv=recv)
-        _native.check(lib.stereo_unpack_keys_dev(merged.data_ptr(), chunk, disp_part.data_ptr(), cost_part.data_ptr(), stream))
-        sharding.gather_slices(disp_part, world, rank)
-        sharding.gather_slices(cost_part, world, rank)
+        # one gather of the merged key slices; rank 0 unpacks the whole frame
+        frame = sharding.gather_slices(merged, world, rank, out=frame_keys)
+        if rank == 0:
+            _native.check(lib.stereo_unpack_keys_dev(frame.data_ptr(), n, disp.data_ptr(), cost.data_ptr(), stream))
 
     def fence() -> None:
         if world > 1:

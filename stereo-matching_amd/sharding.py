@@ -11,7 +11,7 @@ Two partitionings, both taken from how the reference's work decomposes:
   unsharded one for any partition.
   The exchange is an all-to-all: rank r sends pixel slice j of its keys straight to rank j (one
   hop on the point-to-point xGMI mesh, all links busy at once), min-merges the N slices it
-  receives, unpacks its slice and hands it to rank 0.  Ring all-reduce would move the same bytes
+  receives and hands its merged slice to rank 0, which unpacks the frame.  Ring all-reduce would move the same bytes
   over one link at a time.
 
 * Scene-parallel batches (reference stereo.py:722-778 loops scenes sequentially): scenes are
@@ -62,16 +62,22 @@ def exchange_and_merge(keys, world: int, merge_fn: Callable, recv=None):
     return merged
 
 
-def gather_slices(part, world: int, rank: int, dst: int = 0):
-    """Gather equal-length slices on `dst`; returns the concatenated tensor there, None elsewhere."""
+def gather_slices(part, world: int, rank: int, dst: int = 0, out=None):
+    """Gather equal-length slices on `dst`; returns the concatenated tensor there, None elsewhere.
+    `out` (on `dst`, world * len(part) elements) receives the slices in place when given."""
     import torch
     import torch.distributed as dist
 
     if world == 1:
         return part
-    bufs = [torch.empty_like(part) for _ in range(world)] if rank == dst else None
-    dist.gather(part, bufs, dst=dst)
-    return torch.cat(bufs) if rank == dst else None
+    if rank != dst:
+        dist.gather(part, None, dst=dst)
+        return None
+    n = part.numel()
+    if out is None:
+        out = torch.empty(world * n, dtype=part.dtype, device=part.device)
+    dist.gather(part, [out[j * n:(j + 1) * n] for j in range(world)], dst=dst)
+    return out
 
 
 def deal_scenes(sizes: Sequence[int], world: int) -> List[List[int]]:

@@ -67,10 +67,16 @@ def _worker(rank: int, world: int, port: int, out_path: str) -> None:
         d_part, c_part = unpack_keys(merged.numpy().view(np.uint64))
         d_all = sharding.gather_slices(torch.from_numpy(d_part.copy()), world, rank)
         c_all = sharding.gather_slices(torch.from_numpy(c_part.copy()), world, rank)
+        # the path bench.py takes: one gather of the merged key slices into a preallocated frame
+        frame = torch.empty(merged.numel() * world, dtype=torch.int64) if rank == 0 else None
+        got = sharding.gather_slices(merged.contiguous(), world, rank, out=frame)
         if rank == 0:
             dref, cref = orc.aggregate_and_wta(dsi, left, orc.FILTER_GUIDED, 3, 0.0154)
             ok = np.array_equal(d_all.numpy()[:n].reshape(h, w), dref) and np.array_equal(
                 c_all.numpy()[:n].reshape(h, w), cref)
+            d_f, c_f = unpack_keys(got.numpy().view(np.uint64))
+            ok = ok and got is frame and np.array_equal(d_f[:n].reshape(h, w), dref) and np.array_equal(
+                c_f[:n].reshape(h, w), cref)
             with open(out_path, "w") as f:
                 f.write("ok" if ok else "mismatch")
     finally:
