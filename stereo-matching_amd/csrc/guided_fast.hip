@@ -303,16 +303,17 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
 
     // disparities are handed to the wavefronts of the workgroup one at a time
     for (;;) {
-        int dn = 0;
-        if (lane == 0) dn = atomicAdd(t.next_d, 1);
-        dn = __builtin_amdgcn_readfirstlane(dn);
+        // Every lane takes part in the LDS atomic (the counter advances by 64 per wavefront) and no
+        // lane-dependent branch surrounds the hand-out: a `lane == 0` guard here lets the optimiser
+        // specialise the loop for the other lanes, for which the guarded value is a constant.
+        const int dn = __builtin_amdgcn_readfirstlane(atomicAdd(t.next_d, 1)) >> 6;
         const int d = a.d_begin + dn * a.n_slices + (int)blockIdx.z;
         if (d >= a.d_end || dn >= n_disp) break;
         // Every column this wavefront reads lies left of the first valid match (x - d < radius):
         // all costs are `large`, and a constant window filters to exactly that constant.  Only
         // the lowest such disparity can win a tie, so remember it and skip the pass.
         if (!QOUT && tx0 - HALO + 63 - d < R) {
-            if (lane == 0) atomicMin(&t.next_d[1], d);
+            atomicMin(&t.next_d[1], d);
             continue;
         }
         if (interior)

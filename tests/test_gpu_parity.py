@@ -457,3 +457,94 @@ def test_compute_disparity_other_filters_vs_oracle(oracle, filt, kw, okind, orad
             # mismatch must still be a near-tie in the oracle's own layers
             min_agree = 0.5
         assert_wta_matches(d, c, dref, cref, layers, min_agree=min_agree)
+
+
+# ------------------------------------------------------------------ BASELINE-size checks
+
+@pytest.fixture(scope="module")
+def motorcycle_pair():
+    """The bench workload: Motorcycle-perfect shaped synthetic pair (2964 x 2000, dmax 270)."""
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(2000, 2964, 270, 2014)
+    return left, right
+
+
+def test_full_size_strip_matches_oracle(oracle, motorcycle_pair):
+    """Full width, full disparity range: a 120-row strip of the full-frame result against the oracle
+    run on the strip plus the 10 rows either side its filter windows and census offsets reach."""
+    import stereo
+    left, right = motorcycle_pair
+    d, c = stereo.compute_disparity(left, right, 270, guided_eps=0.0154, show_progress=False)
+    y0, y1, halo = 700, 820, 2 * 3 + 4
+    lo, hi = y0 - halo, y1 + halo
+    dref, cref = oracle.compute_disparity(np.ascontiguousarray(left[lo:hi]), np.ascontiguousarray(right[lo:hi]), 270,
+                                          wct_radius=4, radius=3, eps_or_sigma=0.0154)
+    dref, cref = dref[halo:-halo], cref[halo:-halo]
+    ds, cs = d[y0:y1], c[y0:y1]
+    assert rel_err(cs, cref) <= TOL
+    agree = np.mean(ds == dref)
+    assert agree >= 0.999, agree
+    # every mismatch is a near-tie: the winning costs of the two answers differ by less than the tolerance
+    bad = ds != dref
+    assert np.all(np.abs(cs[bad] - cref[bad]) <= TOL * np.maximum(1.0, np.abs(cref[bad])))
+
+
+def test_full_size_kernel_variants_and_shards(motorcycle_pair):
+    """At the bench size: the three fused guided kernels agree, and disparity shards merged with the
+    (cost, d) key minimum reproduce the unsharded frame bit for bit."""
+    import stereo
+    left, right = motorcycle_pair
+    run = lambda **kw: stereo.compute_disparity(left, right, 270, guided_eps=0.0154, show_progress=False, **kw)
+    d0, c0 = run()
+    d1, c1 = _with_kernel(1, run)
+    d2, c2 = _with_kernel(2, run)
+    for dd, cc in ((d1, c1), (d2, c2)):
+        assert rel_err(cc, c0) <= 1e-6
+        assert np.mean(dd == d0) >= 0.9995
+    best_c = np.full(c0.shape, np.inf, dtype=np.float32)
+    best_d = np.zeros(d0.shape, dtype=np.int32)
+    for a, b in ((0, 34), (34, 135), (135, 270)):
+        dd, cc = run(d_begin=a, d_end=b)
+        better = cc < best_c          # shards arrive in ascending d: strict '<' keeps the lower disparity
+        best_c = np.where(better, cc, best_c)
+        best_d[better] = dd[better]
+    assert np.array_equal(best_d, d0) and np.array_equal(best_c, c0)
+
+
+@pytest.mark.parametrize("filt", ["median", "gaussian", "bilateral"])
+def test_fused_filter_shards_merge_bit_exact(filt):
+    """Volume-free median / Gaussian / bilateral kernels: any partition of [0, D) merges to the
+    unsharded result (the median quantises every layer with that layer's own range, so a shard sees
+    the same levels as the full run)."""
+    import stereo
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(200, 420, 64, seed=17)
+    run = lambda **kw: stereo.compute_disparity(left, right, 64, wct_radius=8, filter_type=filt, show_progress=False, **kw)
+    d0, c0 = run()
+    best_c = np.full(c0.shape, np.inf, dtype=np.float32)
+    best_d = np.zeros(d0.shape, dtype=np.int32)
+    for a, b in ((0, 7), (7, 40), (40, 64)):
+        dd, cc = run(d_begin=a, d_end=b)
+        better = cc < best_c
+        best_c = np.where(better, cc, best_c)
+        best_d[better] = dd[better]
+    assert np.array_equal(best_d, d0) and np.array_equal(best_c, c0)
+
+
+@pytest.mark.parametrize("d_begin,d_end", [(60, 61), (100, 116), (0, 270), (250, 270)])
+def test_disparities_beyond_the_first_tiles(d_begin, d_end):
+    """Disparity ranges that leave whole tiles without a valid match (x - d < radius for every column of
+    the tile: those passes are skipped and the lowest skipped disparity takes part in the WTA as an
+    exact `large`).  Ranges whose first disparity is already skipped used to loop forever."""
+    import stereo
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(200, 400, 270, seed=2014)
+    run = lambda: stereo.compute_disparity(left, right, 270, guided_eps=0.0154, show_progress=False,
+                                           d_begin=d_begin, d_end=d_end)
+    d_gen, c_gen = _with_kernel(1, run)
+    for mode in (0, 2):
+        d, c = _with_kernel(mode, run)
+        assert np.array_equal(np.isfinite(c), np.isfinite(c_gen))
+        fin = np.isfinite(c_gen)
+        assert rel_err(c[fin], c_gen[fin]) <= 1e-6
+        assert np.mean(d == d_gen) >= 0.9995
