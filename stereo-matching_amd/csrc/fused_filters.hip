@@ -26,6 +26,7 @@ struct FFArgs {
     CensusCfg cfg;
     int H, W, d_begin, d_end;
     float kern[(2 * FF_MAX_RADIUS + 1) * (2 * FF_MAX_RADIUS + 1)];  // normalised spatial weights, row-major
+    float kern1[2 * FF_MAX_RADIUS + 1];  // Gaussian: normalised 1-D weights
     float denom;          // bilateral: -log2(e) / (2 sigma^2)
     uint32_t *mm;         // median: [d - d_begin][2] order-preserving (min, max) of the cost layer
     uint64_t *keys;
@@ -260,21 +261,23 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
         float outv[FF_ROWS_PER_THREAD];
         const float *win = cb + (q * FF_ROWS_PER_THREAD) * LW + lx;
         if (FILTER == STEREO_FILTER_GAUSSIAN) {
-#pragma unroll
-            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) outv[j] = 0.f;
+            // The reference's weight table exp(-(x^2 + y^2) / 2 sigma^2) / sum (filters.py:24-39) is the outer
+            // product of a normalised 1-D Gaussian with itself up to float32 rounding: rows first (shared
+            // by the four outputs), then columns -- 2 (2r + 1) multiply-adds per output instead of (2r + 1)^2.
+            float hrow[NR];
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
-                float v[K];
+                float h = 0.f;
 #pragma unroll
-                for (int dx = 0; dx < K; ++dx) v[dx] = win[rr * LW + dx];
+                for (int dx = 0; dx < K; ++dx) h = fmaf(win[rr * LW + dx], a.kern1[dx], h);
+                hrow[rr] = h;
+            }
 #pragma unroll
-                for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
-                    const int dy = rr - j;
-                    if (dy >= 0 && dy < K) {
+            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+                float o = 0.f;
 #pragma unroll
-                        for (int dx = 0; dx < K; ++dx) outv[j] = fmaf(v[dx], a.kern[dy * K + dx], outv[j]);
-                    }
-                }
+                for (int dy = 0; dy < K; ++dy) o = fmaf(hrow[j + dy], a.kern1[dy], o);
+                outv[j] = o;
             }
         } else if (FILTER == STEREO_FILTER_BILATERAL) {
             // w = spatial * exp(-(v - c)^2 / (2 sigma^2))  (filters.py:299-304) evaluated as one hardware
@@ -377,6 +380,17 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
     a.mm = d_mm; a.keys = d_keys;
     if (filter_kind != STEREO_FILTER_MEDIAN_U8Q) {
         gaussian_kernel_host(radius, sigma, a.kern);
+        if (filter_kind == STEREO_FILTER_GAUSSIAN) {
+            // float32 exponentials as the reference forms them, normalised in float64
+            const float denom32 = (float)(2.0 * sigma * sigma);
+            double e[2 * FF_MAX_RADIUS + 1], sum = 0.0;
+            for (int t = -radius; t <= radius; ++t) {
+                const float ft = (float)t;
+                e[t + radius] = (double)std::exp(-(ft * ft) / denom32);
+                sum += e[t + radius];
+            }
+            for (int t = 0; t <= 2 * radius; ++t) a.kern1[t] = (float)(e[t] / sum);
+        }
         if (filter_kind == STEREO_FILTER_BILATERAL) {
             const int kk = (2 * radius + 1) * (2 * radius + 1);
             for (int i = 0; i < kk; ++i) a.kern[i] = (float)std::log2((double)a.kern[i]);
