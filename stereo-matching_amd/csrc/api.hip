@@ -4,6 +4,9 @@
 #include <vector>
 
 #include "common.hpp"
+#include <algorithm>
+#include <climits>
+#include <vector>
 
 namespace shp {
 
@@ -236,6 +239,42 @@ static int finish_keys_to_host(uint64_t *d_keys, size_t n, int32_t *out_disp, fl
     return STEREO_OK;
 }
 
+// The reference forms its box sums from integral images (guided_filter.py:33-46,132-137): a NaN or
+// infinity in the guide turns every cumulative sum below and to the right of it into NaN, hence every
+// window whose lower right corner lies there, through both box stages: all outputs at
+// y >= yb - 2r, x >= xb - 2r.  The fused kernels sum windows directly and keep NaNs local, so the host
+// entry points extend the damage to the reference's region (rare path: only when the guide is not
+// finite).  fill(y, x0) is called for every row with the first poisoned column.
+template <typename GT, typename Fill>
+static void poison_like_reference(const GT *guide, int H, int W, int radius, Fill fill) {
+    std::vector<int> first(H, INT32_MAX);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const double v = (double)guide[(size_t)y * W + x];
+            if (!(std::fabs(v) <= 1.7976931348623157e308)) { first[y] = x; break; }
+        }
+    int run = INT32_MAX;
+    std::vector<int> pm(H);
+    for (int y = 0; y < H; ++y) { run = std::min(run, first[y]); pm[y] = run; }
+    for (int y = 0; y < H; ++y) {
+        const int xb = pm[std::min(y + 2 * radius, H - 1)];
+        if (xb != INT32_MAX) fill(y, std::max(xb - 2 * radius, 0));
+    }
+}
+static void poison_disparity(const void *guide, int guide_dtype, int H, int W, int radius, int32_t *disp, float *cost) {
+    auto fill = [&](int y, int x0) {
+        for (int x = x0; x < W; ++x) { disp[(size_t)y * W + x] = 0; cost[(size_t)y * W + x] = INFINITY; }
+    };
+    if (guide_dtype == STEREO_DT_F64) poison_like_reference(static_cast<const double *>(guide), H, W, radius, fill);
+    else if (guide_dtype == STEREO_DT_F32) poison_like_reference(static_cast<const float *>(guide), H, W, radius, fill);
+}
+static int guide_is_finite(const void *d_gmax, bool *finite) {
+    uint32_t w[2] = {0u, 0u};
+    SHP_HIP(hipMemcpy(w, d_gmax, 8, hipMemcpyDeviceToHost));
+    *finite = w[1] == 0u;
+    return STEREO_OK;
+}
+
 }  // namespace shp
 
 using namespace shp;
@@ -406,7 +445,13 @@ int stereo_compute_disparity_host(const void *left, const void *right, int dtype
         SHP_HIP(hipMemcpy(dr.p, hr, n * 4, hipMemcpyHostToDevice));
         SHP_TRY(fused_disparity_dev(dl.as<float>(), dr.as<float>(), H, W, dmax, p, d_begin, d_end, ws.p, L.total,
                                     keys.as<uint64_t>(), nullptr, nullptr));
-        return finish_keys_to_host(keys.as<uint64_t>(), n, out_disp, out_cost);
+        SHP_TRY(finish_keys_to_host(keys.as<uint64_t>(), n, out_disp, out_cost));
+        if (p->filter_kind == STEREO_FILTER_GUIDED && d_begin < d_end) {
+            bool finite = true;
+            SHP_TRY(guide_is_finite(static_cast<unsigned char *>(ws.p) + L.off_gmax, &finite));
+            if (!finite) poison_disparity(hl, STEREO_DT_F32, H, W, p->guided_radius, out_disp, out_cost);
+        }
+        return STEREO_OK;
     }
     // general path: cost layers on the device, then one filter launch chain per layer
     const size_t img_bytes = n * dtype_size(dtype), word_bytes = n * (cfg.word64 ? 8 : 4);
@@ -444,16 +489,18 @@ int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dty
         return STEREO_EINVAL;
     }
     size_t n = (size_t)H * W;
-    DevBuf ddsi, dg, mean, invden, keys, layers;
+    DevBuf ddsi, dg, mean, invden, keys, layers, gmax;
+    bool check_guide = false;
     SHP_TRY(ddsi.alloc(n * (size_t)dmax * 4));
     SHP_TRY(dg.alloc(n * dtype_size(guide_dtype)));
     SHP_TRY(keys.alloc(n * 8));
     SHP_HIP(hipMemcpy(ddsi.p, dsi, n * (size_t)dmax * 4, hipMemcpyHostToDevice));
     SHP_HIP(hipMemcpy(dg.p, guide, n * dtype_size(guide_dtype), hipMemcpyHostToDevice));
     if (p->filter_kind == STEREO_FILTER_GUIDED && fused_guided_supported(p->guided_radius)) {
-        SHP_TRY(mean.alloc(n * 8)); SHP_TRY(invden.alloc(n * 8));
+        SHP_TRY(mean.alloc(n * 8)); SHP_TRY(invden.alloc(n * 8)); SHP_TRY(gmax.alloc(8));
         SHP_TRY(launch_guide_stats(dg.p, guide_dtype, H, W, p->guided_radius, p->guided_eps, mean.as<double>(),
-                                   invden.as<double>(), nullptr, nullptr));
+                                   invden.as<double>(), gmax.p, nullptr));
+        check_guide = d_begin < d_end;
         if (d_begin == d_end) SHP_TRY(launch_fill_keys(keys.as<uint64_t>(), n, nullptr));
         else
             SHP_TRY(launch_fused_guided(nullptr, nullptr, nullptr, ddsi.as<float>(), dg.p, guide_dtype,
@@ -466,7 +513,13 @@ int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dty
         SHP_TRY(layered_aggregate_dev(layers.as<float>() + (size_t)d_begin * n, dg.p, guide_dtype, H, W, p, d_begin,
                                       d_end, keys.as<uint64_t>(), nullptr));
     }
-    return finish_keys_to_host(keys.as<uint64_t>(), n, out_disp, out_cost);
+    SHP_TRY(finish_keys_to_host(keys.as<uint64_t>(), n, out_disp, out_cost));
+    if (check_guide) {
+        bool finite = true;
+        SHP_TRY(guide_is_finite(gmax.p, &finite));
+        if (!finite) poison_disparity(guide, guide_dtype, H, W, p->guided_radius, out_disp, out_cost);
+    }
+    return STEREO_OK;
 }
 
 int stereo_guided_filter_host(const double *guide, const float *src, int H, int W, int radius, double eps,
@@ -475,15 +528,15 @@ int stereo_guided_filter_host(const double *guide, const float *src, int H, int 
     if (radius <= 0) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
     if (!(eps > 0)) { set_error("eps must be positive"); return STEREO_EINVAL; }
     size_t n = (size_t)H * W;
-    DevBuf dg, ds, q;
+    DevBuf dg, ds, q, gmax;
     SHP_TRY(dg.alloc(n * 8)); SHP_TRY(ds.alloc(n * 4)); SHP_TRY(q.alloc(n * 4));
     SHP_HIP(hipMemcpy(dg.p, guide, n * 8, hipMemcpyHostToDevice));
     SHP_HIP(hipMemcpy(ds.p, src, n * 4, hipMemcpyHostToDevice));
     if (fused_guided_supported(radius)) {
         DevBuf mean, invden, keys;
-        SHP_TRY(mean.alloc(n * 8)); SHP_TRY(invden.alloc(n * 8)); SHP_TRY(keys.alloc(n * 8));
+        SHP_TRY(mean.alloc(n * 8)); SHP_TRY(invden.alloc(n * 8)); SHP_TRY(keys.alloc(n * 8)); SHP_TRY(gmax.alloc(8));
         SHP_TRY(launch_guide_stats(dg.p, STEREO_DT_F64, H, W, radius, eps, mean.as<double>(), invden.as<double>(),
-                                   nullptr, nullptr));
+                                   gmax.p, nullptr));
         SHP_TRY(launch_fused_guided(nullptr, nullptr, nullptr, ds.as<float>(), dg.p, STEREO_DT_F64, mean.as<double>(),
                                     invden.as<double>(), H, W, 1, radius, 0, 1, keys.as<uint64_t>(), q.as<float>(), 0,
                                     nullptr));
@@ -494,6 +547,14 @@ int stereo_guided_filter_host(const double *guide, const float *src, int H, int 
         SHP_TRY(layered_guided_apply(ds.as<float>(), H, W, radius, eps, ws.p, q.as<float>(), nullptr));
     }
     SHP_HIP(hipMemcpy(out, q.p, n * 4, hipMemcpyDeviceToHost));
+    if (gmax.p) {
+        bool finite = true;
+        SHP_TRY(guide_is_finite(gmax.p, &finite));
+        if (!finite)
+            poison_like_reference(guide, H, W, radius, [&](int y, int x0) {
+                for (int x = x0; x < W; ++x) out[(size_t)y * W + x] = NAN;
+            });
+    }
     return STEREO_OK;
 }
 

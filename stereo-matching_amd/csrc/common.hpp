@@ -116,7 +116,8 @@ int launch_keys_to_i64(const uint64_t *keys, int64_t *out, size_t n, hipStream_t
 int launch_keys_from_i64(const int64_t *in, uint64_t *keys, size_t n, hipStream_t s);
 
 // guided filter
-// d_gmax (optional, 4 bytes): receives max |guide| as a float32
+// d_gmax (optional, 8 bytes): receives the largest finite |guide| as a float32, then a word that is
+// non-zero when some guide pixel is NaN or infinite
 int launch_guide_stats(const void *d_guide, int guide_dtype, int H, int W, int radius, double eps,
                        double *d_mean, double *d_invden, void *d_gmax, hipStream_t s);
 size_t guide_stats_scratch_bytes(int H, int W, int radius);

@@ -59,13 +59,16 @@ __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__
         hs2[i] = s2;
     }
     __syncthreads();
-    float amax = 0.f;  // max |guide| over the tile, as float32 (NaN sticks through the bit compare)
+    float amax = 0.f;  // max finite |guide| over the tile, as float32
+    bool nonfinite = false;
     for (int i = threadIdx.x; i < GS_TH * GS_TW; i += blockDim.x) {
         int ly = i >> 6, lx = i & 63;
         int gy = y0 + ly, gx = x0 + lx;
         if (gy >= H || gx >= W) continue;
-        float ag = fabsf((float)tile[(ly + R) * LW + lx + R]);
-        amax = (__float_as_uint(ag) > __float_as_uint(amax)) ? ag : amax;
+        const double gv = tile[(ly + R) * LW + lx + R];
+        const float ag = fabsf((float)gv);
+        if (fabs(gv) <= 1.7976931348623157e308) amax = fmaxf(amax, fminf(ag, 3.402823466e38f));
+        else nonfinite = true;
         double s1 = 0.0, s2 = 0.0;
         for (int k = 0; k <= 2 * R; ++k) {
             s1 += hs1[(ly + k) * GS_TW + lx];
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__
         }
         // read first: almost every wavefront sees a value already at least as large
         if ((threadIdx.x & 63) == 0 && b > *static_cast<volatile unsigned int *>(gmax_bits)) atomicMax(gmax_bits, b);
+        if (nonfinite) gmax_bits[1] = 1u;   // second word: some guide pixel is NaN or infinite
     }
 }
 
@@ -100,7 +104,7 @@ int launch_guide_stats(const void *d_guide, int guide_dtype, int H, int W, int r
                        double *d_mean, double *d_invden, void *d_gmax, hipStream_t s) {
     if (H <= 0 || W <= 0) return STEREO_OK;
     unsigned int *gmax_bits = static_cast<unsigned int *>(d_gmax);
-    if (gmax_bits) SHP_HIP(hipMemsetAsync(gmax_bits, 0, 4, s));
+    if (gmax_bits) SHP_HIP(hipMemsetAsync(gmax_bits, 0, 8, s));
     if (radius < 1 || radius > 16) {
         set_error("guide statistics kernel supports radius 1..16, got %d", radius);
         return STEREO_EUNSUPPORTED;

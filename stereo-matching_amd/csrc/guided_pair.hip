@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
 
     if (threadIdx.x == 0) { t.next_d[0] = 0; t.next_d[1] = 0x7fffffff; t.next_d[2] = 0; }
     __syncthreads();
-    bool finite_in = gmax < 3.0e38f;
+    bool finite_in = __float_as_uint(a.gmax[1]) == 0u;
     for (int idx = threadIdx.x; idx < NI * TC; idx += NW * 64) {
         int i = idx / TC, c = idx % TC;
         int gy = ty0 - HALO + i, gx = tx0 - HALO + c;

@@ -548,3 +548,39 @@ def test_disparities_beyond_the_first_tiles(d_begin, d_end):
         fin = np.isfinite(c_gen)
         assert rel_err(c[fin], c_gen[fin]) <= 1e-6
         assert np.mean(d == d_gen) >= 0.9995
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_non_finite_guide_pixels(oracle, mode):
+    """NaN / inf pixels in the left image.  The reference forms its box sums from integral images, so
+    such a pixel at (yb, xb) turns every filtered cost at y >= yb - 2r, x >= xb - 2r into NaN, and a NaN
+    never wins the WTA (stereo.py:167): those pixels keep (0, +inf).  The host entry points reproduce
+    that region; everywhere else the result matches the oracle as usual."""
+    import guided_filter as gf
+    import stereo
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(120, 300, 40, seed=5)
+    left = left.copy()
+    for (y, x), v in zip([(40, 150), (80, 200), (100, 20)], (np.nan, np.inf, -np.inf)):
+        left[y, x] = v
+    dsi = oracle.wct_cost_volume(left, right, 40)
+    with np.errstate(invalid="ignore"):
+        dref, cref, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, 3, 0.0154, want_layers=True)
+    poisoned = ~np.isfinite(cref)
+    yy, xx = np.mgrid[0:120, 0:300]
+    want = ((yy >= 34) & (xx >= 144)) | ((yy >= 74) & (xx >= 194)) | ((yy >= 94) & (xx >= 14))
+    assert np.array_equal(poisoned, want)     # the oracle behaves as described
+    run = lambda: stereo.compute_disparity(left, right, 40, guided_eps=0.0154, show_progress=False)
+    d, c = _with_kernel(mode, run)
+    assert np.array_equal(~np.isfinite(c), poisoned)
+    assert np.all(d[poisoned] == 0) and np.all(np.isposinf(c[poisoned]))
+    assert rel_err(c[~poisoned], cref[~poisoned]) <= TOL
+    assert np.mean(d[~poisoned] == dref[~poisoned]) >= 0.999
+    if mode == 0:
+        d2, c2 = stereo.aggregate_and_wta(dsi, left, 3, 0.0154)
+        assert np.array_equal(~np.isfinite(c2), poisoned) and np.all(d2[poisoned] == 0)
+        assert rel_err(c2[~poisoned], cref[~poisoned]) <= TOL
+        with np.errstate(invalid="ignore"):
+            q = gf.guided_filter(left, dsi[:, :, 7], 3, 0.0154)
+        assert np.array_equal(np.isnan(q), poisoned)
+        assert rel_err(q[~poisoned], layers[7][~poisoned]) <= TOL
