@@ -73,6 +73,7 @@ struct FusedWs {
     size_t words_bytes, plane_f64;
     size_t off_lw, off_rw, off_mean, off_invden, off_gmax, off_mm, total;
 };
+constexpr double FAST_KERNEL_MIN_EPS = 5e-3;
 constexpr int FUSED_MAX_DISPARITIES = 65536;  // per launch; sizes the per-layer min/max scratch of the median path
 static FusedWs fused_ws_layout(int H, int W, int wct_radius) {
     FusedWs w;
@@ -118,8 +119,12 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         SHP_TRY(launch_guide_stats(d_left, STEREO_DT_F32, H, W, p->guided_radius, p->guided_eps, mean, invden,
                                    gmax, s));
         if (d_begin == d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
-        const bool pair = fused_pair_supported(cfg, p->guided_radius) && g_force_kernel == 0;
-        const bool fast = fused_fast_supported(cfg, p->guided_radius) && g_force_kernel != 1;
+        // The fast kernels evaluate the second box stage in float32: its terms grow like 1 / sqrt(eps), and
+        // below this eps their rounding can exceed 1e-5 of a cost unit where the filtered cost is near zero.
+        // Smaller eps takes the general kernel (float64 throughout, bit-identical to the CPU restatement).
+        const bool eps_ok = p->guided_eps >= FAST_KERNEL_MIN_EPS || g_force_kernel == 2;
+        const bool pair = fused_pair_supported(cfg, p->guided_radius) && g_force_kernel == 0 && eps_ok;
+        const bool fast = fused_fast_supported(cfg, p->guided_radius) && g_force_kernel != 1 && eps_ok;
         const int slices = pair ? fused_pair_slices(H, W, p->guided_radius, cfg.word64 != 0, d_end - d_begin)
                            : fast ? fused_fast_slices(H, W, p->guided_radius, d_end - d_begin) : 1;
         if (slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
