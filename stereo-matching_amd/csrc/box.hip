@@ -22,38 +22,36 @@ __global__ __launch_bounds__(64) void integral_cols_kernel(const T *__restrict__
     }
 }
 
-// Inclusive prefix sum across the 64 lanes of a wavefront.
-__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        double n = __shfl_up(v, off, 64);
-        if (lane >= off) v += n;
-    }
-    return v;
-}
-
-// Row pass: one wavefront per row, 64 columns at a time, carry in a register; writes the
-// zero-bordered (H+1, W+1) table.
-__global__ __launch_bounds__(256) void integral_rows_kernel(const double *__restrict__ tmp, int H, int W,
-                                                            double *__restrict__ integral) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // 0..H : row 0 is the zero border
-    if (row > H) return;
+// Row pass: the running sum along a row must add the columns strictly left to right to give the
+// reference's bits for any float64 input (guided_filter.py:42-46), so one lane walks one row.  A
+// wavefront owns 64 rows; 64x64 tiles go through LDS so that global loads and stores stay
+// coalesced along x while each lane scans its own row of the tile.  Writes the zero-bordered
+// (H+1, W+1) table.
+__global__ __launch_bounds__(64) void integral_rows_kernel(const double *__restrict__ tmp, int H, int W,
+                                                           double *__restrict__ integral) {
+    __shared__ double tile[64][65];
+    const int lane = threadIdx.x;
+    const int r0 = blockIdx.x * 64;
+    const int rows = min(64, H - r0);
     const size_t IW = (size_t)W + 1;
-    if (row == 0) {
+    if (blockIdx.x == 0)
         for (int x = lane; x <= W; x += 64) integral[x] = 0.0;
-        return;
-    }
-    const double *src = tmp + (size_t)(row - 1) * W;
-    double *dst = integral + (size_t)row * IW;
-    if (lane == 0) dst[0] = 0.0;
+    if (lane < rows) integral[(size_t)(r0 + lane + 1) * IW] = 0.0;
     double carry = 0.0;
     for (int x0 = 0; x0 < W; x0 += 64) {
-        int x = x0 + lane;
-        double v = x < W ? src[x] : 0.0;
-        double s = wave_inclusive_scan(v, lane) + carry;
-        if (x < W) dst[x + 1] = s;
-        carry = __shfl(s, 63, 64);
+        const int cols = min(64, W - x0);
+        if (lane < cols)
+            for (int i = 0; i < rows; ++i) tile[i][lane] = tmp[(size_t)(r0 + i) * W + x0 + lane];
+        __syncthreads();
+        if (lane < rows)
+            for (int j = 0; j < cols; ++j) {
+                carry = carry + tile[lane][j];
+                tile[lane][j] = carry;
+            }
+        __syncthreads();
+        if (lane < cols)
+            for (int i = 0; i < rows; ++i) integral[(size_t)(r0 + i + 1) * IW + x0 + lane + 1] = tile[i][lane];
+        __syncthreads();
     }
 }
 
@@ -84,7 +82,7 @@ template <typename T>
 static int launch_integral_t(const T *img, int H, int W, double *tmp, double *integral, hipStream_t s) {
     hipLaunchKernelGGL(integral_cols_kernel<T>, dim3(ceil_div(W, 64)), dim3(64), 0, s, img, H, W, tmp);
     SHP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(integral_rows_kernel, dim3(ceil_div(H + 1, 4)), dim3(256), 0, s, tmp, H, W, integral);
+    hipLaunchKernelGGL(integral_rows_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, s, tmp, H, W, integral);
     SHP_LAUNCH_CHECK();
     return STEREO_OK;
 }

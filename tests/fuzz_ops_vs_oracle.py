@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Random small inputs through the stand-alone operators (cost volume, integral image, box mean,
+guided filter, median / Gaussian / bilateral filters, aggregate_and_wta) against the oracle.
+Test infrastructure: `python tests/fuzz_ops_vs_oracle.py N SEED`; tests/test_gpu_fuzz.py runs a batch."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "stereo-matching_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import census  # noqa: E402
+import filters  # noqa: E402
+import guided_filter as gf  # noqa: E402
+import stereo  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from synth import synth_pair_gray  # noqa: E402
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def run_cases(n_cases: int, seed: int, verbose: bool = True) -> int:
+    rng = np.random.default_rng(seed)
+    failures = 0
+    for case in range(n_cases):
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 200))
+        op = str(rng.choice(["dsi", "integral", "box", "guided", "median", "gaussian", "bilateral", "agg"]))
+        tag = f"case {case}: {op} {w}x{h}"
+        problems = []
+        try:
+            if op == "dsi":
+                dmax, radius = int(rng.integers(1, 40)), int(rng.integers(1, 9))
+                base = float(rng.choice([8.0, 8.0, 3.3, 1.0, 0.7]))
+                dt = rng.choice(["f32", "f64", "u8"])
+                left, right, _ = synth_pair_gray(h, w, dmax, seed=case)
+                if dt == "u8":
+                    left, right = (left * 255).astype(np.uint8), (right * 255).astype(np.uint8)
+                elif dt == "f64":
+                    left, right = left.astype(np.float64) * 1.000001, right.astype(np.float64) * 1.000001
+                tag += f" dmax {dmax} r {radius} base {base} {dt}"
+                got = census.compute_wct_cost_volume(left, right, dmax, radius=radius, base_weight=base)
+                want = orc.wct_cost_volume(left, right, dmax, radius=radius, base_weight=base)
+                if not np.array_equal(got, want):
+                    problems.append(f"{int(np.sum(got != want))} cost entries differ")
+            elif op in ("integral", "box"):
+                img = (rng.random((h, w)) * float(rng.choice([1.0, 255.0, 1e-3]))).astype(rng.choice([np.float32, np.float64]))
+                if op == "integral":
+                    if not np.array_equal(gf.integral_image(img), orc.integral_image(img)):
+                        problems.append("integral image differs")
+                else:
+                    r = int(rng.integers(0, 9))
+                    tag += f" r {r}"
+                    if not np.array_equal(gf.box_filter_mean(img, r), orc.box_filter_mean(img, r)):
+                        problems.append("box mean differs")
+            elif op == "guided":
+                r, eps = int(rng.integers(1, 7)), float(rng.choice([0.0154, 0.01, 1e-4, 0.3]))
+                guide = rng.random((h, w)).astype(np.float32)
+                src = (rng.random((h, w)) * 1200).astype(np.float32)
+                tag += f" r {r} eps {eps}"
+                e = rel_err(gf.guided_filter(guide, src, r, eps), orc.guided_filter(guide, src, r, eps))
+                if e > 1e-5:
+                    problems.append(f"rel err {e:.2e}")
+            elif op == "median":
+                r = int(rng.integers(1, 6))
+                method = str(rng.choice(["opencv", "scipy", "vectorized", "naive"]))
+                img = (rng.random((h, w)) * float(rng.choice([1.0, 1200.0]))).astype(np.float32)
+                if rng.random() < 0.2:
+                    img[:] = 3.5
+                tag += f" r {r} {method}"
+                got = filters.median_filter(img, r, method=method)
+                want = orc.median_filter_u8q(img, r) if method == "opencv" else orc.median_filter(img, r)
+                if not np.array_equal(got, want):
+                    problems.append(f"{int(np.sum(got != want))} pixels differ")
+            elif op in ("gaussian", "bilateral"):
+                sigma = float(rng.choice([0.4, 0.8, 1.0, 1.5, 2.2]))
+                r = max(int(np.ceil(3 * sigma)), 1)
+                h, w = max(h, r + 1), max(w, r + 1)
+                img = (rng.random((h, w)) * 1200).astype(np.float32)
+                tag += f" sigma {sigma}"
+                if op == "gaussian":
+                    e = rel_err(filters.gaussian_filter(img, sigma), orc.gaussian_filter(img, sigma))
+                else:
+                    e = rel_err(filters.bilateral_filter(img, sigma), orc.bilateral_filter(img, sigma))
+                if e > 1e-5:
+                    problems.append(f"rel err {e:.2e}")
+            else:
+                dmax = int(rng.integers(1, 30))
+                filt = str(rng.choice(["guided", "median", "gaussian", "bilateral"]))
+                left, right, _ = synth_pair_gray(max(h, 4), max(w, 4), dmax, seed=case)
+                dsi = orc.wct_cost_volume(left, right, dmax)
+                kind = {"guided": orc.FILTER_GUIDED, "median": orc.FILTER_MEDIAN_U8Q, "gaussian": orc.FILTER_GAUSSIAN,
+                        "bilateral": orc.FILTER_BILATERAL}[filt]
+                radius = 3 if filt in ("guided", "median") else 0
+                param = 0.0154 if filt == "guided" else 1.0
+                tag += f" dmax {dmax} {filt}"
+                dref, cref, layers = orc.aggregate_and_wta(dsi, left, kind, radius, param, want_layers=True)
+                d, c = stereo.aggregate_and_wta(dsi, left, 3, 0.0154, filter_type=filt)
+                if filt == "median":
+                    if not (np.array_equal(d, dref) and np.array_equal(c, cref)):
+                        problems.append("median WTA not bit-exact")
+                else:
+                    e = rel_err(c, cref)
+                    if e > 1e-5:
+                        problems.append(f"cost rel err {e:.2e}")
+                    for y, x in np.argwhere(d != dref):
+                        f_at, m = float(layers[d[y, x], y, x]), float(cref[y, x])
+                        if not abs(f_at - m) <= 1e-5 * max(1.0, abs(m)):
+                            problems.append(f"disparity ({y},{x}) is not a near-tie")
+                            break
+        except Exception as exc:  # noqa: BLE001
+            problems.append(f"{type(exc).__name__}: {exc}")
+        if problems:
+            failures += 1
+            print("FAIL", tag, "->", "; ".join(problems), flush=True)
+        if verbose and case % 40 == 39:
+            print(f"... {case + 1} cases, {failures} failures", flush=True)
+    return failures
+
+
+def main() -> None:
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    failures = run_cases(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{n_cases} cases, {failures} failures")
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -10,3 +10,13 @@ def test_random_small_cases_match_oracle(oracle, seed, capsys):
 
     failures = fuzz_vs_oracle.run_cases(60, seed, verbose=False)
     assert failures == 0, capsys.readouterr().out
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_operator_cases_match_oracle(oracle, seed, capsys):
+    """Stand-alone operators: cost volume, integral image, box mean and medians bit-exact; guided,
+    Gaussian, bilateral and aggregate_and_wta within 1e-5 (see tests/fuzz_ops_vs_oracle.py)."""
+    import fuzz_ops_vs_oracle
+
+    failures = fuzz_ops_vs_oracle.run_cases(150, seed, verbose=False)
+    assert failures == 0, capsys.readouterr().out
