@@ -73,6 +73,10 @@ def parse_args():
                          "gaussian / bilateral sigma 1)")
     ap.add_argument("--cpu-rows", type=int, default=160, help="rows of the workload the CPU baseline is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bands", type=int, default=0,
+                    help="row bands whose exchange overlaps the search of the rows below them; 0 = 1 on one GPU, 4 on several")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="with --gpus 1: run the N > 1 code path (RCCL collectives, band pipeline) in a group of one rank")
     return ap.parse_args()
 
 
@@ -122,8 +126,12 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
     lib = _native.lib()
     _native.check(lib.stereo_hip_init(local_rank))
-    if world > 1:
+    use_dist = world > 1 or args.dist_single
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     H, W, D, r_c, seed, desc = WORKLOADS[args.workload]
@@ -138,39 +146,58 @@ def main() -> None:
     _native.check(lib.stereo_fused_workspace_bytes(H, W, params, ctypes.byref(ws_bytes)))
     workspace = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
     n = H * W
-    chunk = sharding.padded_chunk(n, world)
-    n_pad = chunk * world
-    keys = torch.empty(n_pad, dtype=torch.int64, device=dev)
-    keys.fill_(-(1 << 63) + 0)  # never read: the pad only travels through the exchange
     d_begin, d_end = sharding.shard_range(D, world, rank)
-    if world > 1:
-        recv = torch.empty(n_pad, dtype=torch.int64, device=dev)
-        frame_keys = torch.empty(n_pad, dtype=torch.int64, device=dev) if rank == 0 else None
-    full = n_pad if (world > 1 and rank == 0) else n
-    disp = torch.empty(full, dtype=torch.int32, device=dev)
-    cost = torch.empty(full, dtype=torch.float32, device=dev)
+    n_bands = args.bands or (4 if use_dist else 1)
+    disp = torch.empty(n, dtype=torch.int32, device=dev)
+    cost = torch.empty(n, dtype=torch.float32, device=dev)
 
-    def step() -> None:
+    def search(d0, d1, row0, row1, keys) -> None:
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _native.check(lib.stereo_compute_disparity_dev(
-            left.data_ptr(), right.data_ptr(), H, W, D, params, d_begin, d_end, workspace.data_ptr(), ws_bytes.value,
-            keys.data_ptr(), stream))
-        if world == 1:
-            _native.check(lib.stereo_unpack_keys_dev(keys.data_ptr(), n, disp.data_ptr(), cost.data_ptr(), stream))
-            return
-        # every rank sends pixel slice j of its shard's keys to rank j over its direct xGMI link,
-        # min-merges the N slices it receives and hands its merged slice to rank 0
-        def merge(dst, src):
-            _native.check(lib.stereo_merge_keys_dev(dst.data_ptr(), src.data_ptr(), dst.numel(), stream))
+            left.data_ptr() + row0 * W * 4, right.data_ptr() + row0 * W * 4, row1 - row0, W, D, params, d0, d1,
+            workspace.data_ptr(), ws_bytes.value, keys.data_ptr(), stream))
 
-        merged = sharding.exchange_and_merge(keys, world, merge, recv=recv)
-        # one gather of the merged key slices; rank 0 unpacks the whole frame
-        frame = sharding.gather_slices(merged, world, rank, out=frame_keys)
-        if rank == 0:
-            _native.check(lib.stereo_unpack_keys_dev(frame.data_ptr(), n, disp.data_ptr(), cost.data_ptr(), stream))
+    def unpack(keys, count, first, disp_out=disp, cost_out=cost) -> None:
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _native.check(lib.stereo_unpack_keys_dev(keys.data_ptr(), count, disp_out.data_ptr() + first * 4,
+                                                 cost_out.data_ptr() + first * 4, stream))
+
+    def merge(slices, chunk, n_slices) -> None:
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _native.check(lib.stereo_merge_key_slices_dev(slices.data_ptr(), chunk, n_slices, stream))
+
+    if use_dist or n_bands > 1:
+        # The kernel reports finished row bands; a side stream ships each band as soon as it is final: every rank
+        # sends pixel slice j of the band's keys to rank j over its direct xGMI link, min-merges the N slices it
+        # receives and hands its merged slice to rank 0, while the kernel searches the bands below.
+        row_end = (ctypes.c_int32 * 16)()
+        bands_out = ctypes.c_int(0)
+        _native.check(lib.stereo_progress_plan(H, W, params, min(n_bands, 16), row_end, ctypes.byref(bands_out)))
+        n_bands = bands_out.value
+        progress = torch.zeros(48, dtype=torch.int32, device=dev)
+        exchange = sharding.OverlappedExchange(H, W, world, rank, list(row_end[:n_bands]), dev, use_dist=use_dist)
+
+        def search_reporting(keys, epoch) -> None:
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _native.check(lib.stereo_compute_disparity_progress_dev(
+                left.data_ptr(), right.data_ptr(), H, W, D, params, d_begin, d_end, workspace.data_ptr(), ws_bytes.value,
+                keys.data_ptr(), n_bands, progress.data_ptr(), epoch, stream))
+
+        def wait_band(band, epoch) -> None:
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _native.check(lib.stereo_wait_progress_dev(progress.data_ptr(), band, epoch, stream))
+
+        def step() -> None:
+            exchange.run(search_reporting, wait_band, merge, unpack)
+    else:
+        frame_keys = torch.empty(n, dtype=torch.int64, device=dev)
+
+        def step() -> None:
+            search(d_begin, d_end, 0, H, frame_keys)
+            unpack(frame_keys, n, 0)
 
     def fence() -> None:
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -185,15 +212,25 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctypes.c_double(0.0), ctypes.c_int(0)
     _native.check(lib.stereo_profile_end(ctypes.byref(kernel_ms), ctypes.byref(launches)))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    kernel_step_ms = kernel_ms.value / max(launches.value, 1)
+    if use_dist:
+        t = torch.tensor([elapsed, kernel_step_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([kernel_ms.value / max(launches.value, 1)], dtype=torch.float64, device=dev)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kernel_avg_ms = float(k.item())
+        elapsed, kernel_avg_ms = float(t[0].item()), float(t[1].item())
     else:
-        kernel_avg_ms = kernel_ms.value / max(launches.value, 1)
+        kernel_avg_ms = kernel_step_ms
+
+    # untimed self-check of the sharded / banded result against one unsharded whole-frame search on rank 0
+    merge_check = None
+    if rank == 0 and (use_dist or n_bands > 1):
+        ref_keys = torch.empty(n, dtype=torch.int64, device=dev)
+        ref_disp, ref_cost = torch.empty_like(disp), torch.empty_like(cost)
+        search(0, D, 0, H, ref_keys)
+        unpack(ref_keys, n, 0, ref_disp, ref_cost)
+        torch.cuda.synchronize()
+        differ = int((ref_disp != disp).sum().item())
+        rel = float(((ref_cost - cost).abs() / ref_cost.abs().clamp_min(1.0)).max().item())
+        merge_check = {"pixels_differing_from_unsharded": differ, "max_rel_cost_diff": rel, "pixels": n}
 
     if rank == 0:
         evals = H * W * D
@@ -216,7 +253,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": desc, "height": H, "width": W, "dmax": D,
                        "parallelism": "single GPU" if world == 1 else f"disparity range sharded over {world} GPUs, "
-                       "all-to-all + local (cost, d) min merge, gather to rank 0"},
+                       f"all-to-all + local (cost, d) min merge, gather to rank 0, overlapped with the search in {n_bands} row bands"},
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -232,10 +269,12 @@ def main() -> None:
                         "not by HBM",
             },
         }
+        if merge_check is not None:
+            out["merge_check"] = merge_check
         if world == 1 and not args.no_cpu_baseline and args.filter == "guided" and r_c == 4:
             out["cpu_baseline"] = cpu_baseline(left_np, right_np, D, args.cpu_rows)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

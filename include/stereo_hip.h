@@ -141,12 +141,38 @@ int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int 
                                  size_t workspace_bytes, uint64_t *d_keys, void *stream);
 /* keys[i] = min(keys[i], other[i]) -- local merge of two disparity shards. */
 int stereo_merge_keys_dev(uint64_t *d_keys, const uint64_t *d_other, size_t n, void *stream);
+/* The same over n_slices equal-length slices laid end to end (what an all-to-all of key slices
+ * delivers): d_slices[i] = min_j d_slices[j * chunk + i], one pass. */
+int stereo_merge_key_slices_dev(uint64_t *d_slices, size_t chunk, int n_slices, void *stream);
 /* Map keys to a signed-int64-comparable form and back (torch/RCCL reduce int64, not uint64). */
 int stereo_keys_to_i64_dev(const uint64_t *d_keys, int64_t *d_out, size_t n, void *stream);
 int stereo_keys_from_i64_dev(const int64_t *d_in, uint64_t *d_keys, size_t n, void *stream);
 /* Unpack keys into int32 disparity and float32 min cost (never-updated pixels: 0 and +inf). */
 int stereo_unpack_keys_dev(const uint64_t *d_keys, size_t n, int32_t *d_disparity, float *d_min_cost,
                            void *stream);
+
+/* ---- row-band progress: overlap of the multi-GPU exchange with the search ------------------ */
+/* No counterpart in the reference (a single-process CPU program); for callers that merge
+ * disparity shards across GPUs and want to ship the top rows of the frame while the kernel is
+ * still working on the rest.
+ *
+ * stereo_progress_plan splits the frame into at most n_bands row bands (<= 16) whose borders
+ * suit the kernel these parameters select: row_end[b] is the end row (exclusive) of band b,
+ * *bands_out the number of bands actually formed.
+ * stereo_compute_disparity_progress_dev is stereo_compute_disparity_dev plus reporting:
+ * d_progress points to 48 zero-initialised uint32 words owned by the caller; once all keys of
+ * the rows of band b are final, word 16 + b holds `epoch` (use a new, increasing epoch for every
+ * call).  Kernels without in-flight reporting set every flag when they have finished.
+ * n_bands / row_end must come from stereo_progress_plan for the same frame and parameters.
+ * stereo_wait_progress_dev makes `stream` wait (a polling wavefront, bounded to about two
+ * seconds) until band `band` carries `epoch`; enqueue it AFTER the producing call. */
+int stereo_progress_plan(int height, int width, const StereoParams *params, int n_bands, int32_t *row_end,
+                         int *bands_out);
+int stereo_compute_disparity_progress_dev(const float *d_left, const float *d_right, int height, int width, int dmax,
+                                          const StereoParams *params, int d_begin, int d_end, void *d_workspace,
+                                          size_t workspace_bytes, uint64_t *d_keys, int n_bands,
+                                          uint32_t *d_progress, uint32_t epoch, void *stream);
+int stereo_wait_progress_dev(const uint32_t *d_progress, int band, uint32_t epoch, void *stream);
 
 /* Test hook, no counterpart in the reference: selects the fused guided kernel compute_disparity
  * uses, so the variants can be compared on the same input.  0 = the best one that applies

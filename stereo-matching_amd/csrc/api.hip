@@ -93,7 +93,8 @@ static FusedWs fused_ws_layout(int H, int W, int wct_radius) {
 // Fused compute_disparity on device float32 images; keys receive the packed result.
 static int fused_disparity_dev(const float *d_left, const float *d_right, int H, int W, int dmax,
                                const StereoParams *p, int d_begin, int d_end, void *ws, size_t ws_bytes,
-                               uint64_t *d_keys, float *d_q_out, hipStream_t s) {
+                               uint64_t *d_keys, float *d_q_out, hipStream_t s,
+                               const BandProgress *progress = nullptr) {
     SHP_TRY(check_params(p));
     SHP_TRY(check_image_dims(H, W));
     if (dmax <= 0) { set_error("dmax must be a positive integer"); return STEREO_EINVAL; }
@@ -131,7 +132,7 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();
         if (prof) SHP_HIP(hipEventRecord(g_prof.start[g_prof.used], s));
         int rc = pair ? launch_fused_guided_pair(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius,
-                                                 d_begin, d_end, slices, d_keys, d_q_out, s)
+                                                 d_begin, d_end, slices, d_keys, d_q_out, s, progress)
                  : fast ? launch_fused_guided_fast(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius,
                                                  d_begin, d_end, slices, d_keys, d_q_out, s)
                       : launch_fused_guided(lw, rw, &cfg, nullptr, d_left, STEREO_DT_F32, mean, invden, H, W, dmax,
@@ -162,6 +163,15 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         ++g_prof.used;
     }
     return rc;
+}
+
+// Tile height of the kernel fused_disparity_dev dispatches when that kernel reports row-band
+// progress while it runs; 0 when it does not (the flags are then set after the kernel).
+static int progress_tile_rows(const StereoParams *p, const CensusCfg &cfg) {
+    if (p->filter_kind != STEREO_FILTER_GUIDED) return 0;
+    const bool eps_ok = p->guided_eps >= FAST_KERNEL_MIN_EPS;
+    if (!(fused_pair_supported(cfg, p->guided_radius) && g_force_kernel == 0 && eps_ok)) return 0;
+    return pair_tile_height(p->guided_radius, cfg.word64 != 0);
 }
 
 // whether compute_disparity with these parameters runs volume-free
@@ -370,6 +380,60 @@ int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int 
                                static_cast<hipStream_t>(stream));
 }
 
+int stereo_progress_plan(int H, int W, const StereoParams *p, int n_bands, int32_t *row_end, int *bands_out) {
+    SHP_TRY(check_params(p));
+    SHP_TRY(check_image_dims(H, W));
+    if (!row_end || !bands_out || n_bands < 1 || n_bands > PROGRESS_MAX_BANDS) {
+        set_error("1..%d bands and non-null outputs", PROGRESS_MAX_BANDS);
+        return STEREO_EINVAL;
+    }
+    CensusCfg cfg;
+    SHP_TRY(make_census_cfg(p->wct_radius, p->base_weight, &cfg));
+    const int th = progress_tile_rows(p, cfg);
+    int n = 0;
+    if (th > 0) {
+        const int tile_rows = ceil_div(H, th), per_band = ceil_div(tile_rows, n_bands);
+        for (int first = 0; first < tile_rows; first += per_band) row_end[n++] = std::min(H, (first + per_band) * th);
+    } else {
+        n_bands = std::min(n_bands, H);
+        for (int b = 0; b < n_bands; ++b) row_end[n++] = (int)((int64_t)(b + 1) * H / n_bands);
+    }
+    *bands_out = n;
+    return STEREO_OK;
+}
+
+int stereo_compute_disparity_progress_dev(const float *d_left, const float *d_right, int H, int W, int dmax,
+                                          const StereoParams *p, int d_begin, int d_end, void *ws, size_t ws_bytes,
+                                          uint64_t *d_keys, int n_bands, uint32_t *d_progress, uint32_t epoch,
+                                          void *stream) {
+    if (!d_left || !d_right || !p || !ws || !d_keys || !d_progress) { set_error("null pointer"); return STEREO_EINVAL; }
+    if (n_bands < 1 || n_bands > PROGRESS_MAX_BANDS) { set_error("1..%d bands", PROGRESS_MAX_BANDS); return STEREO_EINVAL; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SHP_TRY(check_params(p));
+    CensusCfg cfg;
+    SHP_TRY(make_census_cfg(p->wct_radius, p->base_weight, &cfg));
+    BandProgress pg;
+    pg.words = d_progress;
+    pg.epoch = epoch;
+    const int th = progress_tile_rows(p, cfg);
+    pg.band_tile_rows = th > 0 ? ceil_div(ceil_div(H, th), n_bands) : 0;
+    // the bands the kernel will count must be the ones the plan announced
+    if (th > 0 && ceil_div(ceil_div(H, th), pg.band_tile_rows) != n_bands) {
+        set_error("n_bands = %d does not come from stereo_progress_plan for this frame", n_bands);
+        return STEREO_EINVAL;
+    }
+    SHP_HIP(hipMemsetAsync(d_progress, 0, sizeof(uint32_t) * PROGRESS_MAX_BANDS, s));
+    int rc = fused_disparity_dev(d_left, d_right, H, W, dmax, p, d_begin, d_end, ws, ws_bytes, d_keys, nullptr, s, &pg);
+    // whatever ran (or failed to launch), nobody may be left waiting on this epoch
+    int rc2 = launch_progress_finish(d_progress, n_bands, epoch, s);
+    return rc != STEREO_OK ? rc : rc2;
+}
+
+int stereo_wait_progress_dev(const uint32_t *d_progress, int band, uint32_t epoch, void *stream) {
+    if (!d_progress) { set_error("null pointer"); return STEREO_EINVAL; }
+    return launch_progress_wait(d_progress, band, epoch, static_cast<hipStream_t>(stream));
+}
+
 int stereo_debug_force_general_kernel(int on) {
     g_force_kernel = on;
     return STEREO_OK;
@@ -406,6 +470,10 @@ int stereo_profile_end(double *total_ms, int *launches) {
 
 int stereo_merge_keys_dev(uint64_t *d_keys, const uint64_t *d_other, size_t n, void *stream) {
     return launch_merge_keys(d_keys, d_other, n, static_cast<hipStream_t>(stream));
+}
+int stereo_merge_key_slices_dev(uint64_t *d_slices, size_t chunk, int n_slices, void *stream) {
+    if (!d_slices || n_slices < 1) { set_error("null pointer or no slices"); return STEREO_EINVAL; }
+    return launch_merge_key_slices(d_slices, chunk, n_slices, static_cast<hipStream_t>(stream));
 }
 int stereo_keys_to_i64_dev(const uint64_t *d_keys, int64_t *d_out, size_t n, void *stream) {
     return launch_keys_to_i64(d_keys, d_out, n, static_cast<hipStream_t>(stream));

@@ -268,6 +268,17 @@ __global__ void merge_keys_kernel(uint64_t *__restrict__ keys, const uint64_t *_
         keys[i] = b < a ? b : a;
     }
 }
+// keys[i] = min over the n_slices equal-length slices laid end to end; the result lands in slice 0
+__global__ void merge_key_slices_kernel(uint64_t *__restrict__ slices, size_t chunk, int n_slices) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < chunk; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t m = slices[i];
+        for (int j = 1; j < n_slices; ++j) {
+            const uint64_t v = slices[(size_t)j * chunk + i];
+            m = v < m ? v : m;
+        }
+        slices[i] = m;
+    }
+}
 __global__ void fill_keys_kernel(uint64_t *__restrict__ keys, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         keys[i] = SHP_KEY_INIT;
@@ -292,6 +303,12 @@ int launch_unpack_keys(const uint64_t *keys, size_t n, int32_t *disp, float *cos
 int launch_merge_keys(uint64_t *keys, const uint64_t *other, size_t n, hipStream_t s) {
     if (n == 0) return STEREO_OK;
     hipLaunchKernelGGL(merge_keys_kernel, dim3(ew_grid(n)), dim3(256), 0, s, keys, other, n);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+int launch_merge_key_slices(uint64_t *slices, size_t chunk, int n_slices, hipStream_t s) {
+    if (chunk == 0 || n_slices <= 1) return STEREO_OK;
+    hipLaunchKernelGGL(merge_key_slices_kernel, dim3(ew_grid(chunk)), dim3(256), 0, s, slices, chunk, n_slices);
     SHP_LAUNCH_CHECK();
     return STEREO_OK;
 }

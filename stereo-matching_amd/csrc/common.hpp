@@ -111,6 +111,7 @@ int launch_dsi(const void *d_lw, const void *d_rw, int H, int W, int dmax, const
                hipStream_t s);
 int launch_unpack_keys(const uint64_t *keys, size_t n, int32_t *disp, float *cost, hipStream_t s);
 int launch_merge_keys(uint64_t *keys, const uint64_t *other, size_t n, hipStream_t s);
+int launch_merge_key_slices(uint64_t *slices, size_t chunk, int n_slices, hipStream_t s);
 int launch_fill_keys(uint64_t *keys, size_t n, hipStream_t s);
 int launch_keys_to_i64(const uint64_t *keys, int64_t *out, size_t n, hipStream_t s);
 int launch_keys_from_i64(const int64_t *in, uint64_t *keys, size_t n, hipStream_t s);
@@ -132,10 +133,20 @@ int launch_fused_guided(const void *d_lw, const void *d_rw, const CensusCfg *cfg
 // fast fused kernel (guided_fast.hip): exact census weights, float32 guide, guided radius <= 4
 bool fused_pair_supported(const CensusCfg &cfg, int guided_radius);
 int fused_pair_slices(int H, int W, int guided_radius, bool word64, int n_disp);
+// Progress words of a launch that reports finished row bands (see FastArgs::progress).
+constexpr int PROGRESS_MAX_BANDS = 16;
+struct BandProgress {
+    uint32_t *words;      // device, 2 * PROGRESS_MAX_BANDS words
+    int band_tile_rows;   // tile rows per band (0: the kernel does not report, flags are set after it)
+    uint32_t epoch;
+};
+int pair_tile_height(int guided_radius, bool word64);
 int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
-                             float *d_q_out, hipStream_t s);
+                             float *d_q_out, hipStream_t s, const BandProgress *progress = nullptr);
+int launch_progress_finish(uint32_t *words, int n_bands, uint32_t epoch, hipStream_t s);
+int launch_progress_wait(const uint32_t *words, int band, uint32_t epoch, hipStream_t s);
 bool fused_fast_supported(const CensusCfg &cfg, int guided_radius);
 int fused_fast_slices(int H, int W, int guided_radius, int n_disp);
 int launch_fused_guided_fast(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,

@@ -22,6 +22,12 @@ struct FastArgs {
     float unit;             // value of one cost unit
     uint32_t large_units;   // `large` in cost units
     int atomic_out;
+    // Row-band progress for callers that ship finished rows while the rest is searched:
+    // words[b] counts the finished workgroups of band b, words[16 + b] receives `epoch` when the
+    // band's rows are final in `keys`.  nullptr = no reporting.
+    uint32_t *progress;
+    int band_tile_rows;     // tile rows per band
+    uint32_t epoch;
 };
 
 #define DPP_WAVE_SHL1 0x130

@@ -469,7 +469,28 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
             }
             if (a.atomic_out) atomicMin(reinterpret_cast<unsigned long long *>(&a.keys[(size_t)gy * W + gx]),
                                         (unsigned long long)key);
+            // device-scope store: written through this XCD's L2, so that a reader on another XCD sees it
+            // without this workgroup flushing the whole L2 (which a device-scope fence would do)
+            else if (a.progress) __hip_atomic_store(&a.keys[(size_t)gy * W + gx], key, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
             else a.keys[(size_t)gy * W + gx] = key;
+        }
+    }
+    if (a.progress) {
+        // This workgroup's keys are final.  Every thread waits for its own stores to be performed, the
+        // workgroup meets, and one thread counts the workgroup into its row band; the last workgroup of
+        // the band publishes the band's flag.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the stores above have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int band = (int)blockIdx.y / a.band_tile_rows;
+            const int band_rows = min(a.band_tile_rows, (int)gridDim.y - band * a.band_tile_rows);
+            const uint32_t total = (uint32_t)band_rows * gridDim.x * gridDim.z;
+            if (atomicAdd(&a.progress[band], 1u) + 1u == total) {
+                __hip_atomic_store(&a.progress[PROGRESS_MAX_BANDS + band], a.epoch, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -517,7 +538,7 @@ static int launch_pair_t(const FastArgs &a, hipStream_t s) {
     return a.q_out ? launch_pair_q<RG, WORD64, true>(a, s) : launch_pair_q<RG, WORD64, false>(a, s);
 }
 
-static int pair_tile_height(int guided_radius, bool word64) {
+int pair_tile_height(int guided_radius, bool word64) {
     switch (guided_radius) {
         case 1: return word64 ? PairTile<1, true>::TH : PairTile<1, false>::TH;
         case 2: return word64 ? PairTile<2, true>::TH : PairTile<2, false>::TH;
@@ -545,7 +566,7 @@ int fused_pair_slices(int H, int W, int guided_radius, bool word64, int n_disp) 
 int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
-                             float *d_q_out, hipStream_t s) {
+                             float *d_q_out, hipStream_t s, const BandProgress *progress) {
     if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
     FastArgs a;
     memset(&a, 0, sizeof(a));
@@ -556,6 +577,11 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
     a.radius = cfg.radius; a.unit = cfg.unit;
     a.large_units = (uint32_t)std::lround((double)cfg.large / (double)cfg.unit);
     a.atomic_out = a.n_slices > 1;
+    if (progress && progress->band_tile_rows > 0) {
+        a.progress = progress->words;
+        a.band_tile_rows = progress->band_tile_rows;
+        a.epoch = progress->epoch;
+    }
     const bool w64 = cfg.word64 != 0;
     switch (guided_radius) {
         case 1: return w64 ? launch_pair_t<1, true>(a, s) : launch_pair_t<1, false>(a, s);

@@ -1,0 +1,51 @@
+// Row-band progress words: how a caller learns, while the fused kernel is still running, that
+// the first rows of the frame are final and can be shipped to the other GPUs.
+//
+// words[0 .. 15]   finished workgroups per band (the kernel counts, the launcher clears)
+// words[16 .. 31]  band flags: the launch's epoch once the band's keys are final
+//
+// The flags are set by the fused kernel where it supports it and, in every case, by
+// progress_finish_kernel enqueued right after it, so a waiter never depends on which kernel ran.
+#include "common.hpp"
+
+namespace shp {
+
+__global__ __launch_bounds__(64) void progress_finish_kernel(uint32_t *words, int n_bands, uint32_t epoch) {
+    const int b = threadIdx.x;
+    if (b < n_bands)
+        __hip_atomic_store(&words[PROGRESS_MAX_BANDS + b], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One lane polls the band's flag and sleeps between polls.  Epochs compare modulo 2^32.  The
+// loop is bounded (about two seconds of the 100 MHz wall clock): a producer that never ran must
+// not leave a wavefront spinning forever; the time-out is recorded in words[32 + band].
+__global__ __launch_bounds__(64) void progress_wait_kernel(uint32_t *words, int band, uint32_t epoch) {
+    if (threadIdx.x != 0) return;
+    const uint64_t t0 = wall_clock64();
+    for (;;) {
+        const uint32_t seen = __hip_atomic_load(&words[PROGRESS_MAX_BANDS + band], __ATOMIC_ACQUIRE,
+                                                __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(seen - epoch) >= 0) break;
+        if (wall_clock64() - t0 > 200000000ull) {
+            words[2 * PROGRESS_MAX_BANDS + band] = epoch;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+int launch_progress_finish(uint32_t *words, int n_bands, uint32_t epoch, hipStream_t s) {
+    if (n_bands < 1 || n_bands > PROGRESS_MAX_BANDS) { set_error("1..%d bands", PROGRESS_MAX_BANDS); return STEREO_EINVAL; }
+    hipLaunchKernelGGL(progress_finish_kernel, dim3(1), dim3(64), 0, s, words, n_bands, epoch);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+int launch_progress_wait(const uint32_t *words, int band, uint32_t epoch, hipStream_t s) {
+    if (band < 0 || band >= PROGRESS_MAX_BANDS) { set_error("band %d outside 0..%d", band, PROGRESS_MAX_BANDS - 1); return STEREO_EINVAL; }
+    hipLaunchKernelGGL(progress_wait_kernel, dim3(1), dim3(64), 0, s, const_cast<uint32_t *>(words), band, epoch);
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+}  // namespace shp

@@ -80,6 +80,96 @@ def gather_slices(part, world: int, rank: int, dst: int = 0, out=None):
     return out
 
 
+class _Band:
+    __slots__ = ("y0", "y1", "n", "chunk", "send", "recv", "frame")
+
+
+class OverlappedExchange:
+    """Disparity-sharded search of one frame with the exchange of finished rows overlapped with
+    the search of the remaining ones.
+
+    The fused kernel works through the frame from the top and reports, per row band, when the
+    band's keys are final (stereo_compute_disparity_progress_dev).  A side stream waits for band
+    b, all-to-alls its key slices, min-merges what it receives and hands the merged slice to rank
+    0 (gather), which unpacks it -- while the kernel is still searching the bands below.  Only the
+    last band's exchange is exposed.  The collectives are issued in the same order on every rank
+    (all-to-all, then gather, band by band).  All buffers are allocated once, here.
+
+    row_end[b] is the end row (exclusive) of band b (stereo_progress_plan).
+
+    search_fn(keys, epoch)        enqueue the whole-frame search of this rank's disparities on the
+                                  current stream; `keys`: height * width int64 key bits
+    wait_band_fn(band, epoch)     make the current stream wait until `band` of `epoch` is final
+    merge_fn(slices, chunk, n)    unsigned 64-bit min over the `n` slices of `chunk` keys laid end to end in
+                                  `slices`, into slice 0, on the current stream
+    unpack_fn(keys, n, first)     rank 0: write disparity / cost of `n` pixels from pixel `first`
+    """
+
+    def __init__(self, height: int, width: int, world: int, rank: int, row_end: Sequence[int], device,
+                 use_dist: Optional[bool] = None):
+        import torch
+
+        if not row_end or list(row_end) != sorted(set(row_end)) or row_end[-1] != height or row_end[0] <= 0:
+            raise ValueError("row_end must increase strictly and end at the frame height")
+        self.world, self.rank, self.width, self.height = world, rank, width, height
+        self.use_dist = (world > 1) if use_dist is None else use_dist
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.epoch = 0
+        n = height * width
+        last_first = (row_end[-2] if len(row_end) > 1 else 0) * width
+        last_chunk = padded_chunk(n - last_first, world)
+        # the padded exchange window of the last band may run past the frame: give the buffer room
+        self.keys = torch.empty(max(n, last_first + last_chunk * world), dtype=torch.int64, device=self.device)
+        self.keys.fill_(-(1 << 63))  # pad beyond the frame: travels, is never unpacked
+        self.bands: List[_Band] = []
+        y0 = 0
+        for y1 in row_end:
+            b = _Band()
+            b.y0, b.y1 = y0, y1
+            b.n = (y1 - y0) * width
+            b.chunk = padded_chunk(b.n, world)
+            # a band's padded window may reach into the first pixels of the next band: those
+            # travel as whatever they hold at the time and are never unpacked
+            b.send = self.keys[y0 * width:y0 * width + b.chunk * world]
+            b.recv = torch.empty(b.chunk * world, dtype=torch.int64, device=self.device) if self.use_dist else None
+            b.frame = (torch.empty(b.chunk * world, dtype=torch.int64, device=self.device)
+                       if self.use_dist and rank == 0 else None)
+            self.bands.append(b)
+            y0 = y1
+
+    def run(self, search_fn: Callable, wait_band_fn: Callable, merge_fn: Callable, unpack_fn: Callable) -> None:
+        import contextlib
+
+        import torch
+        import torch.distributed as dist
+
+        self.epoch += 1
+        epoch = self.epoch
+        world, rank = self.world, self.rank
+        search_fn(self.keys[:self.height * self.width], epoch)
+        side_ctx = torch.cuda.stream(self.side) if self.on_gpu else contextlib.nullcontext()
+        with side_ctx:
+            for i, b in enumerate(self.bands):
+                wait_band_fn(i, epoch)
+                if not self.use_dist:
+                    unpack_fn(b.send, b.n, b.y0 * self.width)
+                    continue
+                # one band at a time, start to finish: this stream must not block on the flag of band
+                # i+1 (which may be a long way off) with work of band i still undone
+                dist.all_to_all_single(b.recv, b.send)
+                merge_fn(b.recv, b.chunk, world)
+                merged = b.recv[:b.chunk]
+                parts = [b.frame[j * b.chunk:(j + 1) * b.chunk] for j in range(world)] if rank == 0 else None
+                dist.gather(merged, parts, dst=0)
+                if rank == 0:
+                    unpack_fn(b.frame, b.n, b.y0 * self.width)
+        if self.on_gpu:
+            # the next search overwrites the key buffer, and the caller reads the outputs on its own stream
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
 def deal_scenes(sizes: Sequence[int], world: int) -> List[List[int]]:
     """Longest-first greedy assignment of scene indices to ranks (balanced total work)."""
     if world <= 0:
