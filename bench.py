@@ -230,7 +230,8 @@ def main() -> None:
         torch.cuda.synchronize()
         differ = int((ref_disp != disp).sum().item())
         rel = float(((ref_cost - cost).abs() / ref_cost.abs().clamp_min(1.0)).max().item())
-        merge_check = {"pixels_differing_from_unsharded": differ, "max_rel_cost_diff": rel, "pixels": n}
+        merge_check = {"pixels_differing_from_unsharded": differ, "max_rel_cost_diff": rel, "pixels": n,
+                       "band_waits_timed_out": int((progress[32:48] != 0).sum().item())}
 
     if rank == 0:
         evals = H * W * D

@@ -164,8 +164,9 @@ int stereo_unpack_keys_dev(const uint64_t *d_keys, size_t n, int32_t *d_disparit
  * the rows of band b are final, word 16 + b holds `epoch` (use a new, increasing epoch for every
  * call).  Kernels without in-flight reporting set every flag when they have finished.
  * n_bands / row_end must come from stereo_progress_plan for the same frame and parameters.
- * stereo_wait_progress_dev makes `stream` wait (a polling wavefront, bounded to about two
- * seconds) until band `band` carries `epoch`; enqueue it AFTER the producing call. */
+ * stereo_wait_progress_dev makes `stream` wait (a polling wavefront, bounded to about ten
+ * seconds; a time-out stores `epoch` in word 32 + band) until band `band` carries `epoch`;
+ * enqueue it AFTER the producing call. */
 int stereo_progress_plan(int height, int width, const StereoParams *params, int n_bands, int32_t *row_end,
                          int *bands_out);
 int stereo_compute_disparity_progress_dev(const float *d_left, const float *d_right, int height, int width, int dmax,

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(64) void progress_finish_kernel(uint32_t *words, in
 }
 
 // One lane polls the band's flag and sleeps between polls.  Epochs compare modulo 2^32.  The
-// loop is bounded (about two seconds of the 100 MHz wall clock): a producer that never ran must
+// loop is bounded (about ten seconds of the 100 MHz wall clock): a producer that never ran must
 // not leave a wavefront spinning forever; the time-out is recorded in words[32 + band].
 __global__ __launch_bounds__(64) void progress_wait_kernel(uint32_t *words, int band, uint32_t epoch) {
     if (threadIdx.x != 0) return;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void progress_wait_kernel(uint32_t *words, int 
         const uint32_t seen = __hip_atomic_load(&words[PROGRESS_MAX_BANDS + band], __ATOMIC_ACQUIRE,
                                                 __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int32_t)(seen - epoch) >= 0) break;
-        if (wall_clock64() - t0 > 200000000ull) {
+        if (wall_clock64() - t0 > 1000000000ull) {
             words[2 * PROGRESS_MAX_BANDS + band] = epoch;
             break;
         }
