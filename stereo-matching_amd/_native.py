@@ -82,6 +82,29 @@ def exported_symbols():
     return sorted(list(_SIGNATURES) + ["stereo_hip_last_error", "stereo_hip_version"])
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 with the system
+    library's SONAME.  When torch is imported first, this library binds to torch's copy by SONAME;
+    when this library were loaded first it would bring in the system copy, torch would later add its
+    own, and the second runtime to initialise does not see the GPU ("No HIP GPUs are available").
+    Loading torch's copy here first (torch itself is NOT imported) makes both orders equal.
+    STEREO_HIP_SYSTEM_RUNTIME=1 keeps the system runtime for processes that never import torch."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("STEREO_HIP_SYSTEM_RUNTIME") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
@@ -90,6 +113,7 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with stereo-matching_amd/build.sh "
                 "(there is no CPU fallback for the stereo hot path)"
             )
+        _share_hip_runtime_with_torch()
         handle = ctypes.CDLL(LIB_PATH)
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)

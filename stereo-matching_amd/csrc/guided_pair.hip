@@ -42,6 +42,11 @@ using Pair = T __attribute__((ext_vector_type(2)));  // the two slots of a lane,
 using f2 = Pair<float>;
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Tile column c inside a de-interleaved 128-column LDS row: even columns first, then odd ones.  Lane l
+// owns columns 2l and 2l + 1; with this order the lanes' accesses to either parity are consecutive
+// (no two-way bank conflict from the stride of two elements).
+__device__ __forceinline__ int deint(int c) { return ((c & 1) << 6) | (c >> 1); }
+
 // Per-lane constants of the two slots.
 struct PairLane {
     int x[2];             // image column of the slot's cost and of its final output
@@ -49,7 +54,7 @@ struct PairLane {
     bool x_valid[2];      // census centre valid in x
     double invAX1[2];     // 1 / (columns of the clipped stage-1 window), 0 outside the image
     float cxf[2];         // columns of the clipped output window
-    int c1;               // tile column of slot 0's stage-1 result, clamped to >= 0
+    int c1, c1b;          // de-interleaved positions of the stage-1 columns of slot 0 and slot 1 (clamped to >= 0)
 };
 
 // One disparity of one tile.  MODE 0: general.  MODE 1: every row the tile touches is inside the
@@ -151,10 +156,13 @@ __device__ __forceinline__ void pair_disparity_pass(
         LDS_AS const Pair<WordT> *Lg = lds_lane_ptr(reinterpret_cast<const Pair<WordT> *>(t.L + base * TC + 2 * lane));
         LDS_AS const uint32_t *kg = lds_lane_ptr(reinterpret_cast<const uint32_t *>(t.k + base * TC + 2 * lane));
         LDS_AS const Pair<float> *glog = lds_lane_ptr(reinterpret_cast<const Pair<float> *>(t.glo + base * TC + 2 * lane));
-        LDS_AS const double *mGg = lds_lane_ptr(t.mG + (base - HALO) * TC + pl.c1);
-        LDS_AS const float *invg = lds_lane_ptr(t.inv + (base - HALO) * TC + pl.c1);
+        // stage-1 columns 2l - r and 2l - r + 1 of the two slots (r odd: odd column first)
+        LDS_AS const double *mGg0 = lds_lane_ptr(t.mG + (base - HALO) * TC + pl.c1);
+        LDS_AS const double *mGg1 = lds_lane_ptr(t.mG + (base - HALO) * TC + pl.c1b);
+        LDS_AS const float *invg0 = lds_lane_ptr(t.inv + (base - HALO) * TC + pl.c1);
+        LDS_AS const float *invg1 = lds_lane_ptr(t.inv + (base - HALO) * TC + pl.c1b);
         LDS_AS const Pair<float> *goutg = lds_lane_ptr(reinterpret_cast<const Pair<float> *>(t.gout + (base - 2 * HALO) * TC + 2 * lane));
-        LDS_AS uint64_t *keyg = lds_lane_ptr(t.key + (base - 2 * HALO) * TC + 2 * lane);
+        LDS_AS uint64_t *keyg = lds_lane_ptr(t.key + (base - 2 * HALO) * TC + lane);
         LDS_AS const double *iay1g = lds_lane_ptr(t.iay1 + (base - HALO));
         LDS_AS const float *cy2g = lds_lane_ptr(t.cy2 + (base - 2 * HALO));
         auto fetch_head = [&](int k) {
@@ -165,8 +173,8 @@ __device__ __forceinline__ void pair_disparity_pass(
             r.L[0] = lp.x; r.L[1] = lp.y;
             r.k[0] = (int)(short)(kk & 0xffffu); r.k[1] = (int)kk >> 16;
             r.glo = gp;
-            r.mG[0] = mGg[k * TC]; r.mG[1] = mGg[k * TC + 1];
-            r.inv_f[0] = invg[k * TC]; r.inv_f[1] = invg[k * TC + 1];
+            r.mG[0] = mGg0[k * TC]; r.mG[1] = mGg1[k * TC];
+            r.inv_f[0] = invg0[k * TC]; r.inv_f[1] = invg1[k * TC];
             return r;
         };
         if (!have_head) { cur = fetch_head(0); have_head = true; }
@@ -316,7 +324,7 @@ __device__ __forceinline__ void pair_disparity_pass(
                         }
                         if (!LEAN) qf = (qf == qf) ? qf : __int_as_float(0x7f800000);
                         const unsigned long long key = ((unsigned long long)ordered_bits(qf) << 32) | (uint32_t)d;
-                        __hip_atomic_fetch_min(reinterpret_cast<LDS_AS unsigned long long *>(keyg + k * TC + j), key,
+                        __hip_atomic_fetch_min(reinterpret_cast<LDS_AS unsigned long long *>(keyg + k * TC + j * 64), key,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
@@ -391,10 +399,10 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         int gy = ty0 - RG + j, gx = tx0 - HALO + c;
         bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         const double mg = in ? a.mean[(size_t)gy * W + gx] : 0.0;
-        t.mG[idx] = mg;
+        t.mG[j * TC + deint(c)] = mg;
         const int cyy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1, cxx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
         const float iv = in ? (float)(a.invden[(size_t)gy * W + gx] / (double)(cyy * cxx)) : 0.f;
-        t.inv[idx] = iv;
+        t.inv[j * TC + deint(c)] = iv;
         finite_in = finite_in && fabs(mg) <= 1.0e300 && fabsf(iv) <= 3.0e38f;
     }
     if (!finite_in) t.next_d[2] = 1;  // (after the barrier below it reads 0 unless some thread saw a non-finite input)
@@ -428,7 +436,8 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         pl.invAX1[j] = t.invtab[cx1];
         pl.cxf[j] = (float)cx;
     }
-    pl.c1 = max(2 * lane - RG, 0);
+    pl.c1 = deint(max(2 * lane - RG, 0));
+    pl.c1b = deint(max(2 * lane - RG, 0) + 1);
     const bool interior = (ty0 - HALO >= R) && (ty0 + TH + HALO <= H - R);
     // columns tx0 - 2r .. tx0 - 2r + 127: full filter windows, valid census centres, finite inputs
     const int xlo = tx0 - HALO, xhi = tx0 - HALO + TC - 1;
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         int o = idx / TC, c = idx % TC;
         int gy = ty0 + o, gx = tx0 - HALO + c;
         if (c >= HALO && c < TC - HALO && gy < H && gx < W) {
-            uint64_t key = t.key[idx];
+            uint64_t key = t.key[o * TC + deint(c)];
             if (skipped_d != 0x7fffffff) {
                 const uint64_t kl = make_key(large_f, (uint32_t)skipped_d);
                 key = kl < key ? kl : key;
