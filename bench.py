@@ -106,6 +106,11 @@ def cpu_baseline(left: np.ndarray, right: np.ndarray, dmax: int, rows: int):
 
 def main() -> None:
     args = parse_args()
+    # stdout carries exactly one JSON line: whatever libraries print on the way (RCCL's version banner
+    # goes to stdout) is sent to stderr at the file-descriptor level until the result is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -222,6 +227,14 @@ def main() -> None:
 
     # untimed self-check of the sharded / banded result against one unsharded whole-frame search on rank 0
     merge_check = None
+    if use_dist or n_bands > 1:
+        # one more (untimed) step on poisoned buffers, so that data left over from earlier steps cannot pass
+        for t in [exchange.keys, disp, cost] + [b.recv for b in exchange.bands if b.recv is not None] + \
+                 [b.frame for b in exchange.bands if b.frame is not None]:
+            t.fill_(-1 if t.dtype != torch.float32 else float("nan"))
+        fence()
+        step()
+        fence()
     if rank == 0 and (use_dist or n_bands > 1):
         ref_keys = torch.empty(n, dtype=torch.int64, device=dev)
         ref_disp, ref_cost = torch.empty_like(disp), torch.empty_like(cost)
@@ -274,7 +287,10 @@ def main() -> None:
             out["merge_check"] = merge_check
         if world == 1 and not args.no_cpu_baseline and args.filter == "guided" and r_c == 4:
             out["cpu_baseline"] = cpu_baseline(left_np, right_np, D, args.cpu_rows)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
