@@ -167,33 +167,18 @@ def main() -> None:
         _native.check(lib.stereo_unpack_keys_dev(keys.data_ptr(), count, disp_out.data_ptr() + first * 4,
                                                  cost_out.data_ptr() + first * 4, stream))
 
-    def merge(slices, chunk, n_slices) -> None:
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _native.check(lib.stereo_merge_key_slices_dev(slices.data_ptr(), chunk, n_slices, stream))
-
     if use_dist or n_bands > 1:
         # The kernel reports finished row bands; a side stream ships each band as soon as it is final: every rank
         # sends pixel slice j of the band's keys to rank j over its direct xGMI link, min-merges the N slices it
         # receives and hands its merged slice to rank 0, while the kernel searches the bands below.
-        row_end = (ctypes.c_int32 * 16)()
-        bands_out = ctypes.c_int(0)
-        _native.check(lib.stereo_progress_plan(H, W, params, min(n_bands, 16), row_end, ctypes.byref(bands_out)))
-        n_bands = bands_out.value
-        progress = torch.zeros(48, dtype=torch.int32, device=dev)
-        exchange = sharding.OverlappedExchange(H, W, world, rank, list(row_end[:n_bands]), dev, use_dist=use_dist)
-
-        def search_reporting(keys, epoch) -> None:
-            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _native.check(lib.stereo_compute_disparity_progress_dev(
-                left.data_ptr(), right.data_ptr(), H, W, D, params, d_begin, d_end, workspace.data_ptr(), ws_bytes.value,
-                keys.data_ptr(), n_bands, progress.data_ptr(), epoch, stream))
-
-        def wait_band(band, epoch) -> None:
-            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _native.check(lib.stereo_wait_progress_dev(progress.data_ptr(), band, epoch, stream))
+        sharded = sharding.ShardedFrameSearch(H, W, D, params, world, rank, dev, n_bands=n_bands, use_dist=use_dist)
+        n_bands = sharded.n_bands
+        exchange, progress = sharded.exchange, sharded.progress
+        if rank == 0:
+            disp, cost = sharded.disparity, sharded.min_cost
 
         def step() -> None:
-            exchange.run(search_reporting, wait_band, merge, unpack)
+            sharded.run(left.view(-1), right.view(-1))
     else:
         frame_keys = torch.empty(n, dtype=torch.int64, device=dev)
 

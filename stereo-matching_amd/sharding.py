@@ -170,6 +170,84 @@ class OverlappedExchange:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
 
 
+class ShardedFrameSearch:
+    """compute_disparity of one frame with the disparity range split over the ranks of the default
+    process group (reference stereo.py:177-245 is the single-process original).  Device-resident:
+    float32 gray images in, int32 disparity and float32 min cost out on rank 0; every buffer is
+    allocated here, once.  Built on the library's device entry points and OverlappedExchange.
+
+    Only parameter sets with a fused kernel are accepted (stereo_compute_disparity_dev raises
+    NotImplementedError for the others at the first run).
+    """
+
+    def __init__(self, height: int, width: int, dmax: int, params, world: int, rank: int, device, n_bands: int = 0,
+                 use_dist: Optional[bool] = None):
+        import ctypes
+
+        import torch
+
+        import _native
+
+        self._native, self._ctypes, self._torch = _native, ctypes, torch
+        self.lib = _native.lib()
+        self.H, self.W, self.D, self.params = height, width, dmax, params
+        self.world, self.rank, self.device = world, rank, torch.device(device)
+        self.use_dist = (world > 1) if use_dist is None else use_dist
+        self.d_begin, self.d_end = shard_range(dmax, world, rank)
+        nbytes = ctypes.c_size_t(0)
+        _native.check(self.lib.stereo_fused_workspace_bytes(height, width, params, ctypes.byref(nbytes)))
+        self.ws_bytes = nbytes.value
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        row_end = (ctypes.c_int32 * 16)()
+        bands = ctypes.c_int(0)
+        want = n_bands or (4 if self.use_dist else 1)
+        _native.check(self.lib.stereo_progress_plan(height, width, params, max(1, min(want, 16)), row_end, ctypes.byref(bands)))
+        self.n_bands = bands.value
+        self.progress = torch.zeros(48, dtype=torch.int32, device=self.device)
+        self.exchange = OverlappedExchange(height, width, world, rank, list(row_end[:self.n_bands]), self.device,
+                                           use_dist=self.use_dist)
+        n = height * width
+        self.disparity = torch.zeros(n, dtype=torch.int32, device=self.device) if rank == 0 else None
+        self.min_cost = torch.full((n,), float("inf"), dtype=torch.float32, device=self.device) if rank == 0 else None
+        self._left = self._right = None
+
+    def _stream(self):
+        return self._ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _search(self, keys, epoch) -> None:
+        self._native.check(self.lib.stereo_compute_disparity_progress_dev(
+            self._left.data_ptr(), self._right.data_ptr(), self.H, self.W, self.D, self.params, self.d_begin, self.d_end,
+            self.workspace.data_ptr(), self.ws_bytes, keys.data_ptr(), self.n_bands, self.progress.data_ptr(), epoch,
+            self._stream()))
+
+    def _wait(self, band, epoch) -> None:
+        self._native.check(self.lib.stereo_wait_progress_dev(self.progress.data_ptr(), band, epoch, self._stream()))
+
+    def _merge(self, slices, chunk, n_slices) -> None:
+        self._native.check(self.lib.stereo_merge_key_slices_dev(slices.data_ptr(), chunk, n_slices, self._stream()))
+
+    def _unpack(self, keys, count, first) -> None:
+        self._native.check(self.lib.stereo_unpack_keys_dev(keys.data_ptr(), count, self.disparity.data_ptr() + first * 4,
+                                                           self.min_cost.data_ptr() + first * 4, self._stream()))
+
+    def run(self, left, right):
+        """left, right: contiguous float32 device tensors of H * W elements.  Enqueues one frame on the
+        current stream (+ the exchange's side stream) and returns (disparity, min_cost) flat device
+        tensors on rank 0, (None, None) elsewhere.  No host synchronisation."""
+        torch = self._torch
+        for img in (left, right):
+            if img.dtype != torch.float32 or img.numel() != self.H * self.W or not img.is_contiguous() or \
+                    img.device != self.device:
+                raise ValueError("images must be contiguous float32 tensors of H * W elements on the search's device")
+        self._left, self._right = left, right
+        self.exchange.run(self._search, self._wait, self._merge, self._unpack)
+        return self.disparity, self.min_cost
+
+    def band_waits_timed_out(self) -> int:
+        """Band waits that gave up (a producer that never ran); 0 in a healthy run.  Synchronises."""
+        return int((self.progress[32:48] != 0).sum().item())
+
+
 def deal_scenes(sizes: Sequence[int], world: int) -> List[List[int]]:
     """Longest-first greedy assignment of scene indices to ranks (balanced total work)."""
     if world <= 0:

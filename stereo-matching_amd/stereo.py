@@ -210,6 +210,70 @@ def compute_disparity(
     return disparity, min_cost
 
 
+def compute_disparity_sharded(
+    left_gray: np.ndarray,
+    right_gray: np.ndarray,
+    dmax: int,
+    world: int,
+    rank: int,
+    local_rank: int = 0,
+    use_dist: Optional[bool] = None,
+    **kwargs,
+) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
+    """compute_disparity (reference stereo.py:177-245) with the disparity range split over the `world`
+    ranks of the initialised torch.distributed process group, one GPU per rank.  Every rank passes the
+    same images and keyword arguments (those of compute_disparity); rank 0 returns
+    (disparity, min_cost), the other ranks (None, None).  The merged result is the unsharded one bit
+    for bit (per-pixel minimum of (cost, disparity) keys).
+
+    Raises NotImplementedError for inputs the device-resident path does not take -- float64 images,
+    non-finite guide pixels, parameters without a fused kernel -- so that the caller can run
+    compute_disparity on one rank instead.
+    """
+    import torch
+
+    import sharding
+
+    left_gray = np.asarray(left_gray)
+    right_gray = np.asarray(right_gray)
+    height, width = ensure_same_shape(left_gray, right_gray)
+    if dmax <= 0:
+        raise ValueError("dmax must be a positive integer")
+    filter_key = str(kwargs.get("filter_type", DEFAULT_FILTER_TYPE)).strip().lower()
+    if filter_key not in _SUPPORTED:
+        raise ValueError(f"filter_type must be one of {_SUPPORTED}")
+    if int(kwargs.get("wct_radius", DEFAULT_WCT_RADIUS)) <= 0:
+        raise ValueError("radius must be a positive integer")
+    params = _filter_params(
+        filter_key, kwargs.get("wct_radius", DEFAULT_WCT_RADIUS), kwargs.get("base_weight", DEFAULT_BASE_WEIGHT),
+        kwargs.get("guided_radius", DEFAULT_GUIDED_RADIUS), kwargs.get("guided_eps", DEFAULT_GUIDED_EPS),
+        kwargs.get("median_radius", DEFAULT_MEDIAN_RADIUS), kwargs.get("median_method", DEFAULT_MEDIAN_METHOD),
+        kwargs.get("median_block_rows", DEFAULT_MEDIAN_BLOCK_ROWS), kwargs.get("gaussian_sigma", DEFAULT_GAUSSIAN_SIGMA),
+        kwargs.get("bilateral_sigma", DEFAULT_BILATERAL_SIGMA))
+    for img in (left_gray, right_gray):
+        # float32 holds uint8 / uint16 / float32 images exactly; wider types would lose comparison order
+        if img.dtype not in (np.float32, np.uint8, np.uint16):
+            raise NotImplementedError(f"the sharded path takes float32, uint8 or uint16 images, got {img.dtype}")
+    if height == 0 or width == 0:
+        raise NotImplementedError("empty image")
+    left32 = np.ascontiguousarray(left_gray, dtype=np.float32)
+    right32 = np.ascontiguousarray(right_gray, dtype=np.float32)
+    if not np.isfinite(left32).all():
+        raise NotImplementedError("non-finite guide pixels: use compute_disparity, which reproduces the reference's NaN region")
+    _native.require_gpu()
+    device = torch.device("cuda", local_rank)
+    search = sharding.ShardedFrameSearch(height, width, int(dmax), params, world, rank, device, use_dist=use_dist)
+    left_dev = torch.from_numpy(left32).to(device).view(-1)
+    right_dev = torch.from_numpy(right32).to(device).view(-1)
+    disparity, min_cost = search.run(left_dev, right_dev)
+    torch.cuda.synchronize(device)
+    if search.band_waits_timed_out():
+        raise RuntimeError("a row band was never reported finished: the search kernel did not run")
+    if rank != 0:
+        return None, None
+    return disparity.view(height, width).cpu().numpy(), min_cost.view(height, width).cpu().numpy()
+
+
 # --------------------------------------------------------------------------------------------
 # Result images
 # --------------------------------------------------------------------------------------------
@@ -451,7 +515,8 @@ def _validate_args(args: argparse.Namespace, dataset_root: Path, ndisp_map: Dict
 def _run_scene(args: argparse.Namespace, run_dir: Path, left_path: Path, right_path: Path, gt_path: Path,
                gt_mask_path: Path, dmax: int, output_metrics: Optional[Path], dataset_name: str,
                all_datasets: bool, print_metrics: bool,
-               progress_callback: Optional[Callable[[int, int, str], None]] = None) -> Dict[str, float]:
+               progress_callback: Optional[Callable[[int, int, str], None]] = None,
+               shard: Optional[Tuple[int, int, int]] = None) -> Dict[str, float]:
     """One scene: read, gray, match, write disparity.png / disparity_color.png / disparity.npz,
     evaluate, write metrics.json and params.json  (reference stereo.py:642-709)."""
     run_dir.mkdir(parents=True, exist_ok=True)
@@ -459,6 +524,26 @@ def _run_scene(args: argparse.Namespace, run_dir: Path, left_path: Path, right_p
                                                                     "disparity.npz"))
     left_gray = to_gray(read_image(str(left_path)), normalize=True)
     right_gray = to_gray(read_image(str(right_path)), normalize=True)
+    matcher_kwargs = dict(
+        wct_radius=args.wct_radius, base_weight=args.base_weight, guided_radius=args.guided_radius,
+        guided_eps=args.guided_eps, filter_type=args.filter, median_radius=args.median_radius,
+        median_method=args.median_method, median_block_rows=args.median_block_rows,
+        gaussian_sigma=args.gaussian_sigma, bilateral_sigma=args.bilateral_sigma)
+    if shard is not None:
+        # (world, rank, local_rank): every rank searches its share of the disparities, rank 0 carries on
+        world, rank, local_rank = shard
+        try:
+            disparity, min_cost = compute_disparity_sharded(left_gray, right_gray, dmax, world, rank, local_rank,
+                                                            use_dist=True, **matcher_kwargs)
+        except NotImplementedError:
+            disparity = min_cost = None
+            if rank == 0:
+                disparity, min_cost = compute_disparity(left_gray, right_gray, dmax=dmax, show_progress=False,
+                                                        **matcher_kwargs)
+        if rank != 0:
+            return {}
+        return _finish_scene(args, run_dir, disparity, min_cost, dmax, output_gray, output_color, output_npz, left_path,
+                             right_path, gt_path, gt_mask_path, output_metrics, dataset_name, all_datasets, print_metrics)
     disparity, min_cost = compute_disparity(
         left_gray, right_gray, dmax=dmax, wct_radius=args.wct_radius, base_weight=args.base_weight,
         guided_radius=args.guided_radius, guided_eps=args.guided_eps, filter_type=args.filter,
@@ -466,6 +551,15 @@ def _run_scene(args: argparse.Namespace, run_dir: Path, left_path: Path, right_p
         median_block_rows=args.median_block_rows, gaussian_sigma=args.gaussian_sigma,
         bilateral_sigma=args.bilateral_sigma, show_progress=progress_callback is None,
         progress_callback=progress_callback)
+    return _finish_scene(args, run_dir, disparity, min_cost, dmax, output_gray, output_color, output_npz, left_path,
+                         right_path, gt_path, gt_mask_path, output_metrics, dataset_name, all_datasets, print_metrics)
+
+
+def _finish_scene(args: argparse.Namespace, run_dir: Path, disparity: np.ndarray, min_cost: np.ndarray, dmax: int,
+                  output_gray: Path, output_color: Path, output_npz: Path, left_path: Path, right_path: Path,
+                  gt_path: Path, gt_mask_path: Path, output_metrics: Optional[Path], dataset_name: str,
+                  all_datasets: bool, print_metrics: bool) -> Dict[str, float]:
+    """Outputs and evaluation of one matched scene  (reference stereo.py:668-709)."""
     _save_disparity_image(disparity, dmax, str(output_gray))
     _save_disparity_color_image(disparity, dmax, str(output_color))
     save_disparity_npz(str(output_npz), disparity, min_cost)
@@ -568,8 +662,9 @@ def main(argv: Optional[Sequence[str]] = None, dataset_root: str = "dataset", re
     """Command-line entry  (reference stereo.py:712-812): --left/--right/--gt/--gt-mask/--dmax,
     --dataset <scene>, or --all-datasets; results go to result/<timestamp>/.
 
-    Under `python -m torch.distributed.run --nproc-per-node N stereo.py --all-datasets` every rank
-    takes one GPU and a share of the scenes; other modes run on rank 0's GPU only."""
+    Under `python -m torch.distributed.run --nproc-per-node N stereo.py ...` every rank takes one GPU:
+    --all-datasets deals the scenes to the ranks, a single scene is searched by all ranks together,
+    each on its share of the disparity range."""
     args = _parse_args(argv)
     root = Path(dataset_root)
     ndisp_map: Dict[str, int] = {}
@@ -581,11 +676,13 @@ def main(argv: Optional[Sequence[str]] = None, dataset_root: str = "dataset", re
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     _native.require_gpu()
     _native.check(_native.lib().stereo_hip_init(local_rank))
-    if world > 1:
+    # STEREO_FORCE_PROCESS_GROUP=1 takes the multi-rank route with a single rank (rehearsal on one GPU)
+    if world > 1 or os.environ.get("STEREO_FORCE_PROCESS_GROUP") == "1":
         import torch
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         names: List[Optional[str]] = [None]
@@ -596,8 +693,8 @@ def main(argv: Optional[Sequence[str]] = None, dataset_root: str = "dataset", re
         try:
             if args.all_datasets:
                 _run_all_datasets(args, root, ndisp_map, run_dir, world, rank)
-            elif rank == 0:
-                _run_single(args, root, ndisp_map, run_dir)
+            else:
+                _run_single(args, root, ndisp_map, run_dir, shard=(world, rank, local_rank))
             dist.barrier()
         finally:
             dist.destroy_process_group()
@@ -609,7 +706,8 @@ def main(argv: Optional[Sequence[str]] = None, dataset_root: str = "dataset", re
     _run_single(args, root, ndisp_map, run_dir)
 
 
-def _run_single(args: argparse.Namespace, root: Path, ndisp_map: Dict[str, int], run_dir: Path) -> None:
+def _run_single(args: argparse.Namespace, root: Path, ndisp_map: Dict[str, int], run_dir: Path,
+                shard: Optional[Tuple[int, int, int]] = None) -> None:
     """--dataset <scene> or explicit --left/--right/--gt/--gt-mask  (reference stereo.py:779-812)."""
     if args.dataset:
         left, right, gt, gt_mask, dmax = _resolve_scene_inputs(root, args.dataset, ndisp_map, args.dmax)
@@ -618,7 +716,7 @@ def _run_single(args: argparse.Namespace, root: Path, ndisp_map: Dict[str, int],
         left, right, gt, gt_mask, dmax, name = (Path(args.left), Path(args.right), Path(args.gt), Path(args.gt_mask),
                                                 args.dmax, "")
     _run_scene(args, run_dir, left, right, gt, gt_mask, dmax, output_metrics=run_dir / "metrics.json",
-               dataset_name=name, all_datasets=False, print_metrics=True)
+               dataset_name=name, all_datasets=False, print_metrics=shard is None or shard[1] == 0, shard=shard)
 
 
 if __name__ == "__main__":

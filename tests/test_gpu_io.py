@@ -187,3 +187,57 @@ def test_eval_npz_tool(gold, tmp_path, capsys):
     assert "PBM:" in capsys.readouterr().out
     with pytest.raises(ValueError):
         eval_npz.main(["--npz", npz, "--gt", gt, "--gt_mask", mask, "--key", "nope"])
+
+
+@pytest.mark.parametrize("filt,kw", [("guided", {}), ("median", {}), ("gaussian", {"gaussian_sigma": 0.8}),
+                                     ("guided", {"guided_radius": 6})])
+def test_compute_disparity_sharded_equals_plain(filt, kw):
+    """The multi-GPU entry point of the package on one rank (no process group): same result as
+    compute_disparity; parameters without a fused kernel are refused so that the caller can fall back."""
+    import stereo
+    from synth import synth_pair_gray
+
+    left, right, _ = synth_pair_gray(150, 260, 40, seed=9)
+    if kw.get("guided_radius") == 6:
+        with pytest.raises(NotImplementedError):
+            stereo.compute_disparity_sharded(left, right, 40, world=1, rank=0, filter_type=filt, **kw)
+        return
+    d0, c0 = stereo.compute_disparity(left, right, 40, filter_type=filt, show_progress=False, **kw)
+    d1, c1 = stereo.compute_disparity_sharded(left, right, 40, world=1, rank=0, filter_type=filt, **kw)
+    assert d1.dtype == np.int32 and c1.dtype == np.float32 and d1.shape == d0.shape
+    assert np.array_equal(d0, d1) and np.array_equal(c0, c1)
+    bad = left.copy()
+    bad[3, 4] = np.nan
+    with pytest.raises(NotImplementedError):
+        stereo.compute_disparity_sharded(bad, right, 40, world=1, rank=0, filter_type=filt, **kw)
+    with pytest.raises(NotImplementedError):
+        stereo.compute_disparity_sharded(left.astype(np.float64), right.astype(np.float64), 40, world=1, rank=0)
+
+
+def test_cli_single_scene_in_a_process_group(oracle, tmp_path):
+    """`torch.distributed.run ... stereo.py --dataset X`: all ranks search one scene together.  One GPU here, so a
+    group of one rank: RCCL collectives, side stream and band flags run, the split is trivial."""
+    import subprocess
+    import sys
+
+    import stereo_io
+    from conftest import PKG_DIR
+
+    root = tmp_path / "dataset"
+    _write_scene(str(root / "Alpha-perfect"), 120, 200, 24, 11)
+    (root / "ndisp_summary.csv").write_text("scene,ndisp\nAlpha-perfect,24\n", encoding="utf-8")
+    result = tmp_path / "result"
+    code = (f"import sys; sys.path.insert(0, {PKG_DIR!r})\nimport stereo\n"
+            f"stereo.main(['--dataset', 'Alpha-perfect'], dataset_root={str(root)!r}, result_root={str(result)!r})\n")
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641",
+               STEREO_FORCE_PROCESS_GROUP="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    runs = sorted(os.listdir(result))
+    assert len(runs) == 1
+    disp, cost = stereo_io.load_disparity_npz(str(result / runs[0] / "disparity.npz"))
+    want_d, want_c, gt, mask = _expected_scene(oracle, str(root / "Alpha-perfect"), 24)
+    assert np.mean(disp == want_d) >= 0.999
+    metrics = json.loads((result / runs[0] / "metrics.json").read_text())
+    pbm, rms, n = oracle.pbm_rms(disp, gt, mask, 2.0)
+    assert metrics["pbm"] == pbm and "PBM:" in out.stdout
