@@ -62,6 +62,37 @@ def measured_hbm_traffic(workload: str):
     return None
 
 
+def counter_ratios(workload: str):
+    """LDS bank-conflict rate and vector-ALU busy fraction of the dominant kernel from the same committed
+    counter summary (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; SQ_ACTIVE_INST_VALU * 4 / SIMDs / GRBM_GUI_ACTIVE
+    with both counters summed over the eight XCDs, 1024 SIMDs)."""
+    if workload != "motorcycle" or not os.path.exists(PMC_SUMMARY):
+        return None, None
+    try:
+        with open(PMC_SUMMARY) as fh:
+            summary = json.load(fh)
+        for name, c in summary.items():
+            if DOMINANT_KERNEL in name:
+                lds = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None
+                valu = (c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
+                        if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_ACTIVE_INST_VALU") else None)
+                return (round(lds, 4) if lds is not None else None, round(valu, 4) if valu is not None else None)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+def host_cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,7 +102,7 @@ def parse_args():
     ap.add_argument("--filter", choices=sorted(FILTERS), default="guided",
                     help="aggregation filter (median = the reference's default uint8-quantised method, radius 3; "
                          "gaussian / bilateral sigma 1)")
-    ap.add_argument("--cpu-rows", type=int, default=160, help="rows of the workload the CPU baseline is timed on")
+    ap.add_argument("--cpu-rows", type=int, default=600, help="rows of the workload the CPU baseline is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bands", type=int, default=0,
                     help="row bands whose exchange overlaps the search of the rows below them; 0 = 1 on one GPU, 4 on several")
@@ -100,7 +131,7 @@ def cpu_baseline(left: np.ndarray, right: np.ndarray, dmax: int, rows: int):
         "cores": threads,
         "kind": "port",
         "sample": f"top {rows} of {left.shape[0]} rows, full width {left.shape[1]}, dmax={dmax} "
-                  f"({evals / 1e6:.1f} M evals in {dt:.1f} s; host has {os.cpu_count()} CPUs)",
+                  f"({evals / 1e6:.1f} M evals in {dt:.1f} s; host: {host_cpu_model()}, {os.cpu_count()} CPUs)",
     }
 
 
@@ -231,6 +262,21 @@ def main() -> None:
         merge_check = {"pixels_differing_from_unsharded": differ, "max_rel_cost_diff": rel, "pixels": n,
                        "band_waits_timed_out": int((progress[32:48] != 0).sum().item())}
 
+    copy_gbs = None
+    if rank == 0:
+        # device-to-device copy bandwidth of this box (read + write bytes), the practical HBM ceiling
+        src = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * src.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
     if rank == 0:
         evals = H * W * D
         ms_per_step = elapsed / args.steps * 1e3
@@ -261,6 +307,9 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "compulsory_frac": round(H * W * 16 / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 if kernel_avg_ms > 0 else None,
+                "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+                "lds_bank_conflict_rate": counter_ratios(args.workload)[0] if world == 1 and args.filter == "guided" else None,
+                "valu_busy": counter_ratios(args.workload)[1] if world == 1 and args.filter == "guided" else None,
                 "note": "DSI-equivalent % of HBM peak: 8 B per pixel-disparity (a float32 cost volume written once "
                         "and read once, which the fused kernel never materialises) + 16 B per pixel; traffic = "
                         "measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate run of this "
