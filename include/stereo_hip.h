@@ -178,7 +178,8 @@ int stereo_wait_progress_dev(const uint32_t *d_progress, int band, uint32_t epoc
 /* Test hook, no counterpart in the reference: selects the fused guided kernel compute_disparity
  * uses, so the variants can be compared on the same input.  0 = the best one that applies
  * (default), 1 = the general kernel (float64 sums exchanged through LDS), 2 = the fast kernel
- * with one image column per lane (the default fast kernel gives every lane two columns). */
+ * with one image column per lane (the default fast kernel gives every lane two columns).  Mode 1
+ * also makes the fused uint8-median kernel take its plain bisection instead of the bit-sliced count. */
 int stereo_debug_force_general_kernel(int mode);
 
 /* Timing of the dominant (fused) kernel with HIP events recorded on the launch stream, for

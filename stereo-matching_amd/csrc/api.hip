@@ -157,7 +157,7 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
     const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();
     if (prof) SHP_HIP(hipEventRecord(g_prof.start[g_prof.used], s));
     int rc = launch_fused_filter(lw, rw, cfg, H, W, p->filter_kind, radius, sigma, d_begin, d_end,
-                                 reinterpret_cast<uint32_t *>(base + L.off_mm), d_keys, s);
+                                 reinterpret_cast<uint32_t *>(base + L.off_mm), d_keys, s, g_force_kernel == 1);
     if (prof) {
         SHP_HIP(hipEventRecord(g_prof.stop[g_prof.used], s));
         ++g_prof.used;

@@ -159,7 +159,7 @@ bool fused_filter_supported(int filter_kind, int radius);
 size_t fused_filter_minmax_bytes(int n_disp);
 int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg, int H, int W, int filter_kind,
                         int radius, double sigma, int d_begin, int d_end, uint32_t *d_mm, uint64_t *d_keys,
-                        hipStream_t s);
+                        hipStream_t s, bool plain_median = false);
 
 int launch_dsi_layers(const void *d_lw, const void *d_rw, int H, int W, int d_begin, int d_end, const CensusCfg &cfg,
                       float *d_layers, hipStream_t s);

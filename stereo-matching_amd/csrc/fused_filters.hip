@@ -30,6 +30,7 @@ struct FFArgs {
     float denom;          // bilateral: -log2(e) / (2 sigma^2)
     uint32_t *mm;         // median: [d - d_begin][2] order-preserving (min, max) of the cost layer
     uint64_t *keys;
+    int plain_median;     // test hook: take the plain bisection instead of the bit-sliced count
 };
 
 __device__ __forceinline__ int ff_reflect101(int i, int n) {
@@ -164,6 +165,27 @@ __device__ __forceinline__ void median_bisect(const float *win, int tlo, int thi
     }
 }
 
+// ---- bit-sliced counting median (7 x 7 windows whose bytes span fewer than 32 levels) --------------
+// A byte b of the tile becomes the 32-bit mask of the levels t >= v, v = b - tlo (255, the quantised
+// `large`, takes level 31, which no other byte reaches).  Bit t of a mask says "this element is <= level
+// t", so adding masks bit position by bit position counts, for all 32 levels at once, the elements not
+// above each level.  The additions are carry-save adders on whole words (two three-input logic
+// instructions each): 7 masks of a column -> a 3-bit count per level held in three words; 7 such
+// columns -> a 6-bit count per level; the word of the predicate "count >= 25" has its lowest set bit at
+// the median level.  Column counts are shared through LDS by the seven windows that contain the column.
+__device__ __forceinline__ uint32_t bs_xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+__device__ __forceinline__ uint32_t bs_maj3(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | (c & (a | b)); }
+// seven one-bit words -> their 3-bit sum (b0 + 2 b1 + 4 b2)
+__device__ __forceinline__ void bs_count7(const uint32_t *m, uint32_t &b0, uint32_t &b1, uint32_t &b2) {
+    const uint32_t x1 = bs_xor3(m[0], m[1], m[2]), y1 = bs_maj3(m[0], m[1], m[2]);
+    const uint32_t x2 = bs_xor3(m[3], m[4], m[5]), y2 = bs_maj3(m[3], m[4], m[5]);
+    b0 = bs_xor3(x1, x2, m[6]);
+    const uint32_t y3 = bs_maj3(x1, x2, m[6]);
+    b1 = bs_xor3(y1, y2, y3);
+    b2 = bs_maj3(y1, y2, y3);
+}
+constexpr int BS_CW = 72;  // row pitch of the column-count planes (70 columns used)
+
 // ---- pass 2: cost -> filter -> WTA ------------------------------------------------------------------
 template <int FILTER, bool WORD64, int RAD>
 __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
@@ -176,7 +198,10 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
     __shared__ float cbuf[2][NP];
     // median: min / max byte of the cost tiles of disparities d, d + 1, d + 2 (slot = index mod 3); a slot is
     // reset two iterations before it is used, after the barrier that ends its last readers
-    __shared__ uint32_t trange_buf[3][2];
+    __shared__ uint32_t trange_buf[3][3];   // [slot][min byte, max byte other than 255, some byte is 255]
+    // bit-sliced median: 3-bit column counts, [plane][tile row][halo column]
+    constexpr bool BITSLICED = MEDIAN && RAD == 3;
+    __shared__ uint32_t colcnt[BITSLICED ? 3 * FF_TH * BS_CW : 1];
 
     const WordT *lw = static_cast<const WordT *>(a.lw);
     const WordT *rw = static_cast<const WordT *>(a.rw);
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
     for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) best[j] = SHP_KEY_INIT;
 
     if (MEDIAN) {
-        if (tid < 3) { trange_buf[tid][0] = 255u; trange_buf[tid][1] = 0u; }
+        if (tid < 3) { trange_buf[tid][0] = 255u; trange_buf[tid][1] = 0u; trange_buf[tid][2] = 0u; }
         __syncthreads();
     }
     for (int d = a.d_begin; d < a.d_end; ++d) {
@@ -224,7 +249,7 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             qinv = flat ? 0.f : (float)((dhi - dlo) / 255.0);
         }
         uint32_t *trange = trange_buf[(d - a.d_begin) % 3];
-        uint32_t mylo = 255u, myhi = 0u;
+        uint32_t mylo = 255u, myhi = 0u, my255 = 0u;
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const int idx = tid + j * FF_THREADS;
@@ -233,29 +258,32 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                 float s = __fmul_rn(__fsub_rn(c, qlo), qscale);
                 s = fminf(fmaxf(s, 0.f), 255.f);
                 const uint32_t b = flat ? 0u : (uint32_t)rintf(s);
-                mylo = min(mylo, b); myhi = max(myhi, b);   // (a thread's surplus slot repeats a tile pixel)
+                mylo = min(mylo, b);   // (a thread's surplus slot repeats a tile pixel)
+                if (b == 255u) my255 = 1u; else myhi = max(myhi, b);
                 c = __uint_as_float(b);
             }
             if (idx < NP) cb[idx] = c;
         }
         if (MEDIAN) {
-            // one LDS atomic pair per wavefront: (255 - min) and max travel through the lanes in one word
+            // one LDS atomic triple per wavefront: (255 - min), max and the 255 flag travel through the lanes in one word
             uint32_t nlo = 255u - mylo;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t other = (uint32_t)__shfl_xor((int)((nlo << 8) | myhi), off, 64);
-                nlo = max(nlo, other >> 8);
+                const uint32_t other = (uint32_t)__shfl_xor((int)((my255 << 16) | (nlo << 8) | myhi), off, 64);
+                my255 |= other >> 16;
+                nlo = max(nlo, (other >> 8) & 255u);
                 myhi = max(myhi, other & 255u);
             }
             if ((tid & 63) == 0) {
                 atomicMin(&trange[0], 255u - nlo);
                 atomicMax(&trange[1], myhi);
+                if (my255) atomicOr(&trange[2], 1u);
             }
         }
         __syncthreads();
         if (MEDIAN && tid == 0) {
             uint32_t *later = trange_buf[(d - a.d_begin + 2) % 3];
-            later[0] = 255u; later[1] = 0u;
+            later[0] = 255u; later[1] = 0u; later[2] = 0u;
         }
 
         float outv[FF_ROWS_PER_THREAD];
@@ -312,11 +340,82 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) outv[j] = (wsum[j] <= 0.f) ? c[j] : __fdiv_rn(vsum[j], wsum[j]);
         } else {
             // the bytes of this tile (halo included) lie in [tlo, thi]: so do all its medians.  Cost
-            // layers mostly hold a narrow band of levels, and then five values fit a word (6-bit fields).
-            const int tlo = (int)trange[0], thi = (int)trange[1];
+            // layers mostly hold a narrow band of levels (plus 255 where a cost is `large`).
+            const int tlo = (int)trange[0], thi2 = max((int)trange[1], tlo), has255 = (int)trange[2];
+            const int thi = has255 ? 255 : thi2;
             int med[FF_ROWS_PER_THREAD];
-            if (thi - tlo < 32) median_bisect<K, 6, LW>(win, tlo, thi, med);
-            else median_bisect<K, 10, LW>(win, tlo, thi, med);
+            if (BITSLICED && thi2 - tlo <= 30 && !a.plain_median) {
+                // phase 1: 3-bit counts of the four 7-row column segments under this thread's outputs, for halo
+                // column lx; the six columns beyond 63 are taken by the first lanes of wavefront 0
+                auto column_counts = [&](int c, int qq) {
+                    uint32_t m[NR];
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) {
+                        const uint32_t b = __float_as_uint(cb[(qq * FF_ROWS_PER_THREAD + rr) * LW + c]);
+                        m[rr] = 0xffffffffu << (b == 255u ? 31u : b - (uint32_t)tlo);
+                    }
+#pragma unroll
+                    for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+                        uint32_t b0, b1, b2;
+                        bs_count7(m + j, b0, b1, b2);
+                        const int o = (qq * FF_ROWS_PER_THREAD + j) * BS_CW + c;
+                        colcnt[o] = b0;
+                        colcnt[FF_TH * BS_CW + o] = b1;
+                        colcnt[2 * FF_TH * BS_CW + o] = b2;
+                    }
+                };
+                column_counts(lx, q);
+                if (tid < 4 * (LW - FF_TW)) column_counts(FF_TW + tid % (LW - FF_TW), tid / (LW - FF_TW));
+                __syncthreads();
+                // phase 2: add the seven columns of each window, find the first level with count >= 25
+#pragma unroll
+                for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+                    const uint32_t *row = colcnt + (q * FF_ROWS_PER_THREAD + j) * BS_CW + lx;
+                    uint32_t u[3][3];  // u[p]: 3-bit sum of plane p over the 7 columns
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        uint32_t m[K];
+#pragma unroll
+                        for (int dx = 0; dx < K; ++dx) m[dx] = row[pl * FF_TH * BS_CW + dx];
+                        bs_count7(m, u[pl][0], u[pl][1], u[pl][2]);
+                    }
+                    // S = U0 + 2 U1 + 4 U2, bit planes s0 .. s5 (S <= 49)
+                    const uint32_t s0 = u[0][0];
+                    const uint32_t s1 = u[0][1] ^ u[1][0], c2 = u[0][1] & u[1][0];
+                    const uint32_t x4 = bs_xor3(u[0][2], u[1][1], u[2][0]), y4 = bs_maj3(u[0][2], u[1][1], u[2][0]);
+                    const uint32_t s2 = x4 ^ c2, c4 = x4 & c2;
+                    const uint32_t x8 = bs_xor3(u[1][2], u[2][1], y4), y8 = bs_maj3(u[1][2], u[2][1], y4);
+                    const uint32_t s3 = x8 ^ c4, c8 = x8 & c4;
+                    const uint32_t s4 = bs_xor3(u[2][2], y8, c8), s5 = bs_maj3(u[2][2], y8, c8);
+                    // S >= 25 = 16 + 8 + 1
+                    const uint32_t ge = s5 | (s4 & s3 & (s2 | s1 | s0));
+                    const int t = __builtin_ctz(ge);   // bit 31 is always set: all 49 elements are <= level 31
+                    med[j] = t == 31 ? (has255 ? 255 : tlo + 31) : tlo + t;
+                }
+            } else if (BITSLICED) {
+                // Bytes other than 255 more than 30 levels apart.  Census costs never get here (a cost that is
+                // not `large` is at most a tenth of it, so it quantises to 26 or less above the minimum); the
+                // plain bisection below, which re-reads the window from LDS at every step, keeps the kernel
+                // correct for any input without the registers of the packed variant.
+#pragma unroll 1
+                for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+                    int lo = tlo, hi = thi;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        int cnt = 0;
+#pragma unroll 1
+                        for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < K; ++dx) cnt += (int)__float_as_uint(win[(j + dy) * LW + dx]) <= mid;
+                        if (cnt > (K * K) / 2) hi = mid; else lo = mid + 1;
+                    }
+                    med[j] = lo;
+                }
+            } else if (thi - tlo < 32) {
+                median_bisect<K, 6, LW>(win, tlo, thi, med);
+            } else {
+                median_bisect<K, 10, LW>(win, tlo, thi, med);
+            }
 #pragma unroll
             for (int j = 0; j < FF_ROWS_PER_THREAD; ++j)
                 outv[j] = flat ? qlo : __fadd_rn(__fmul_rn((float)med[j], qinv), qlo);
@@ -369,7 +468,7 @@ static int launch_ff_w(const FFArgs &a, int radius, hipStream_t s) {
 // d_mm: scratch of fused_filter_minmax_bytes(d_end - d_begin) bytes (median only)
 int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg, int H, int W, int filter_kind,
                         int radius, double sigma, int d_begin, int d_end, uint32_t *d_mm, uint64_t *d_keys,
-                        hipStream_t s) {
+                        hipStream_t s, bool plain_median) {
     if (H <= 0 || W <= 0) return STEREO_OK;
     if (!fused_filter_supported(filter_kind, radius)) { set_error("unsupported fused filter"); return STEREO_EUNSUPPORTED; }
     if ((size_t)H * W > 0x7fffffffu) { set_error("image too large for the fused filter kernels"); return STEREO_EUNSUPPORTED; }
@@ -377,7 +476,7 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
     FFArgs a;
     memset(&a, 0, sizeof(a));
     a.lw = d_lw; a.rw = d_rw; a.cfg = cfg; a.H = H; a.W = W; a.d_begin = d_begin; a.d_end = d_end;
-    a.mm = d_mm; a.keys = d_keys;
+    a.mm = d_mm; a.keys = d_keys; a.plain_median = plain_median ? 1 : 0;
     if (filter_kind != STEREO_FILTER_MEDIAN_U8Q) {
         gaussian_kernel_host(radius, sigma, a.kern);
         if (filter_kind == STEREO_FILTER_GAUSSIAN) {

@@ -584,3 +584,17 @@ def test_non_finite_guide_pixels(oracle, mode):
             q = gf.guided_filter(left, dsi[:, :, 7], 3, 0.0154)
         assert np.array_equal(np.isnan(q), poisoned)
         assert rel_err(q[~poisoned], layers[7][~poisoned]) <= TOL
+
+
+@pytest.mark.parametrize("wct_radius", [4, 8])
+def test_fused_median_counting_and_bisection_agree(wct_radius):
+    """The fused uint8 median finds each 7 x 7 median by bit-sliced counting; its plain bisection (kept for
+    tiles whose bytes span more than 30 levels, which census costs never produce) must give the same maps.
+    Both are also covered against the oracle by the other median tests (default path)."""
+    import stereo
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(150, 333, 48, seed=21)
+    run = lambda: stereo.compute_disparity(left, right, 48, wct_radius=wct_radius, filter_type="median", show_progress=False)
+    d0, c0 = _with_kernel(0, run)
+    d1, c1 = _with_kernel(1, run)
+    assert np.array_equal(d0, d1) and np.array_equal(c0, c1)
