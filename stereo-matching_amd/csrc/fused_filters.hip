@@ -54,35 +54,64 @@ __device__ __forceinline__ float ff_cost(const WordT *__restrict__ rw, const Cen
 }
 
 // ---- pass 1 (median only): min / max of every cost layer ---------------------------------------
-template <typename WordT>
+// One wavefront owns MM_ROWS rows x 512 columns: 8 x MM_ROWS pixels per lane whose left words stay in
+// registers over the disparity loop, so that the wavefront-wide reduction and the two global atomics
+// are paid once per 2048 pixels and disparity.  EXACT: the cost is an integer number of units
+// (field_sum) and is compared as such; `large` enters through a flag.
+constexpr int MM_ROWS = 4;
+template <typename WordT, bool EXACT>
 __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restrict__ lw, const WordT *__restrict__ rw,
                                                          CensusCfg cfg, int H, int W, int d_begin, int d_end,
                                                          uint32_t *__restrict__ mm) {
-    constexpr int PPT = 8;  // pixels per thread: columns x0 + lane + 64 j of one row
+    constexpr int PPT = 8;  // pixels per lane and row: columns x0 + lane + 64 j
     const int lane = threadIdx.x & 63;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * MM_ROWS;
     const int x0 = blockIdx.x * (64 * PPT);
-    if (y >= H) return;
+    if (y0 >= H) return;
     const int R = cfg.radius;
-    const bool yvalid = y >= R && y < H - R;
-    const int ro = y * W;
-    WordT lword[PPT];
-    bool lvalid[PPT], inside[PPT];
+    WordT lword[MM_ROWS][PPT];
+    uint32_t valid_bits = 0u, inside_bits = 0u;  // bit r * PPT + j
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int x = x0 + lane + 64 * j;
-        inside[j] = x < W;
-        const int xc = inside[j] ? x : W - 1;
-        lword[j] = lw[ro + xc];
-        lvalid[j] = yvalid && xc >= R && xc < W - R;
-    }
-    for (int d = d_begin; d < d_end; ++d) {
-        uint32_t lo = 0xffffffffu, hi = 0u;
+    for (int r = 0; r < MM_ROWS; ++r) {
+        const int y = min(y0 + r, H - 1);
+        const bool yin = y0 + r < H, yvalid = y >= R && y < H - R;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            const int x = min(x0 + lane + 64 * j, W - 1);
-            const uint32_t k = f32_to_ordered(ff_cost<WordT>(rw, cfg, lword[j], lvalid[j], ro, x, d));
-            if (inside[j]) { lo = min(lo, k); hi = max(hi, k); }
+            const int x = x0 + lane + 64 * j;
+            const bool in = yin && x < W;
+            const int xc = min(x, W - 1);
+            lword[r][j] = lw[y * W + xc];
+            if (in) inside_bits |= 1u << (r * PPT + j);
+            if (in && yvalid && xc >= R && xc < W - R) valid_bits |= 1u << (r * PPT + j);
+        }
+    }
+    const uint32_t large_key = f32_to_ordered(cfg.large);
+    for (int d = d_begin; d < d_end; ++d) {
+        uint32_t lo = 0xffffffffu, hi = 0u;
+        bool any_large = false;
+#pragma unroll
+        for (int r = 0; r < MM_ROWS; ++r) {
+            const int ro = min(y0 + r, H - 1) * W;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int x = min(x0 + lane + 64 * j, W - 1);
+                const bool in = (inside_bits >> (r * PPT + j)) & 1u;
+                const bool ok = ((valid_bits >> (r * PPT + j)) & 1u) && x - d >= R;
+                if (EXACT) {
+                    const uint32_t u = field_sum((WordT)(lword[r][j] ^ rw[ro + (ok ? x - d : x)]));
+                    if (ok) { lo = min(lo, u); hi = max(hi, u); }
+                    any_large = any_large || (in && !ok);
+                } else {
+                    const uint32_t k = f32_to_ordered(ff_cost<WordT>(rw, cfg, lword[r][j], ok || ((valid_bits >> (r * PPT + j)) & 1u), ro, x, d));
+                    if (in) { lo = min(lo, k); hi = max(hi, k); }
+                }
+            }
+        }
+        if (EXACT) {
+            // units -> order-preserving float keys; a lane without a valid pixel keeps the neutral elements
+            lo = lo == 0xffffffffu ? lo : f32_to_ordered((float)lo * cfg.unit);
+            hi = (lo == 0xffffffffu && hi == 0u) ? 0u : f32_to_ordered((float)hi * cfg.unit);
+            if (any_large) { lo = min(lo, large_key); hi = max(hi, large_key); }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -502,13 +531,17 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
             const int nd = d_end - d_begin;
             hipLaunchKernelGGL(minmax_fill_kernel, dim3(ceil_div(nd, 256)), dim3(256), 0, s, d_mm, nd);
             SHP_LAUNCH_CHECK();
-            dim3 grid(ceil_div(W, 64 * 8), ceil_div(H, 4));
-            if (cfg.word64)
-                hipLaunchKernelGGL(cost_minmax_kernel<uint64_t>, grid, dim3(256), 0, s, static_cast<const uint64_t *>(d_lw),
+            dim3 grid(ceil_div(W, 64 * 8), ceil_div(H, 4 * MM_ROWS));
+            const bool exact = cfg.exact && cfg.unit > 0.f;
+            if (cfg.word64) {
+                auto kern = exact ? cost_minmax_kernel<uint64_t, true> : cost_minmax_kernel<uint64_t, false>;
+                hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, static_cast<const uint64_t *>(d_lw),
                                    static_cast<const uint64_t *>(d_rw), cfg, H, W, d_begin, d_end, d_mm);
-            else
-                hipLaunchKernelGGL(cost_minmax_kernel<uint32_t>, grid, dim3(256), 0, s, static_cast<const uint32_t *>(d_lw),
+            } else {
+                auto kern = exact ? cost_minmax_kernel<uint32_t, true> : cost_minmax_kernel<uint32_t, false>;
+                hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, static_cast<const uint32_t *>(d_lw),
                                    static_cast<const uint32_t *>(d_rw), cfg, H, W, d_begin, d_end, d_mm);
+            }
             SHP_LAUNCH_CHECK();
             return launch_ff_w<STEREO_FILTER_MEDIAN_U8Q>(a, radius, s);
         }
