@@ -300,6 +300,7 @@ const char *stereo_hip_last_error(void) { return g_err; }
 const char *stereo_hip_version(void) { return "stereo_hip 0.1 (gfx950)"; }
 
 int stereo_hip_device_count(int *count) {
+    if (!count) { set_error("null pointer"); return STEREO_EINVAL; }
     if (!count) return STEREO_EINVAL;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -318,6 +319,7 @@ int stereo_hip_init(int device) {
 }
 
 int stereo_generate_offsets(int radius, int32_t *out) {
+    if (!out) { set_error("null pointer"); return STEREO_EINVAL; }
     static const int dirs[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {1, -1}, {-1, 1}, {-1, -1}};
     if (radius <= 0 || !out) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
     int n = 0;
@@ -331,12 +333,14 @@ int stereo_generate_offsets(int radius, int32_t *out) {
 }
 
 int stereo_compute_weights(const int32_t *offsets, int n, double base_weight, float *out) {
+    if (!offsets || !out) { set_error("null pointer"); return STEREO_EINVAL; }
     if (n < 0 || (n > 0 && (!offsets || !out))) { set_error("bad offsets"); return STEREO_EINVAL; }
     for (int i = 0; i < n; ++i) out[i] = (float)(base_weight / std::ldexp(1.0, offsets[3 * i + 2] - 1));
     return STEREO_OK;
 }
 
 int stereo_large_value(int radius, double base_weight, float *out) {
+    if (!out) { set_error("null pointer"); return STEREO_EINVAL; }
     CensusCfg cfg;
     SHP_TRY(make_census_cfg(radius, base_weight, &cfg));
     *out = cfg.large;
@@ -345,6 +349,7 @@ int stereo_large_value(int radius, double base_weight, float *out) {
 
 int stereo_wct_cost_volume_host(const void *left, const void *right, int dtype, int H, int W, int dmax, int radius,
                                 double base_weight, float *out_dsi) {
+    if (!left || !right || !out_dsi) { set_error("null pointer"); return STEREO_EINVAL; }
     if (dmax <= 0) { set_error("dmax must be a positive integer"); return STEREO_EINVAL; }
     SHP_TRY(check_image_dims(H, W));
     if (dtype != STEREO_DT_F32 && dtype != STEREO_DT_F64 && dtype != STEREO_DT_U8) {
@@ -376,11 +381,13 @@ int stereo_fused_workspace_bytes(int H, int W, const StereoParams *p, size_t *by
 int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int H, int W, int dmax,
                                  const StereoParams *p, int d_begin, int d_end, void *ws, size_t ws_bytes,
                                  uint64_t *d_keys, void *stream) {
+    if (!d_left || !d_right || !p || !ws || !d_keys) { set_error("null pointer"); return STEREO_EINVAL; }
     return fused_disparity_dev(d_left, d_right, H, W, dmax, p, d_begin, d_end, ws, ws_bytes, d_keys, nullptr,
                                static_cast<hipStream_t>(stream));
 }
 
 int stereo_progress_plan(int H, int W, const StereoParams *p, int n_bands, int32_t *row_end, int *bands_out) {
+    if (!p) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_params(p));
     SHP_TRY(check_image_dims(H, W));
     if (!row_end || !bands_out || n_bands < 1 || n_bands > PROGRESS_MAX_BANDS) {
@@ -454,6 +461,7 @@ int stereo_profile_begin(int max_launches) {
 }
 
 int stereo_profile_end(double *total_ms, int *launches) {
+    if (!total_ms || !launches) { set_error("null pointer"); return STEREO_EINVAL; }
     double total = 0.0;
     for (int i = 0; i < g_prof.used; ++i) {
         SHP_HIP(hipEventSynchronize(g_prof.stop[i]));
@@ -469,6 +477,7 @@ int stereo_profile_end(double *total_ms, int *launches) {
 }
 
 int stereo_merge_keys_dev(uint64_t *d_keys, const uint64_t *d_other, size_t n, void *stream) {
+    if (n && (!d_keys || !d_other)) { set_error("null pointer"); return STEREO_EINVAL; }
     return launch_merge_keys(d_keys, d_other, n, static_cast<hipStream_t>(stream));
 }
 int stereo_merge_key_slices_dev(uint64_t *d_slices, size_t chunk, int n_slices, void *stream) {
@@ -476,18 +485,22 @@ int stereo_merge_key_slices_dev(uint64_t *d_slices, size_t chunk, int n_slices, 
     return launch_merge_key_slices(d_slices, chunk, n_slices, static_cast<hipStream_t>(stream));
 }
 int stereo_keys_to_i64_dev(const uint64_t *d_keys, int64_t *d_out, size_t n, void *stream) {
+    if (n && (!d_keys || !d_out)) { set_error("null pointer"); return STEREO_EINVAL; }
     return launch_keys_to_i64(d_keys, d_out, n, static_cast<hipStream_t>(stream));
 }
 int stereo_keys_from_i64_dev(const int64_t *d_in, uint64_t *d_keys, size_t n, void *stream) {
+    if (n && (!d_in || !d_keys)) { set_error("null pointer"); return STEREO_EINVAL; }
     return launch_keys_from_i64(d_in, d_keys, n, static_cast<hipStream_t>(stream));
 }
 int stereo_unpack_keys_dev(const uint64_t *d_keys, size_t n, int32_t *d_disp, float *d_cost, void *stream) {
+    if (n && (!d_keys || !d_disp || !d_cost)) { set_error("null pointer"); return STEREO_EINVAL; }
     return launch_unpack_keys(d_keys, n, d_disp, d_cost, static_cast<hipStream_t>(stream));
 }
 
 int stereo_compute_disparity_host(const void *left, const void *right, int dtype, int H, int W, int dmax,
                                   const StereoParams *p, int d_begin, int d_end, int32_t *out_disp,
                                   float *out_cost) {
+    if (!left || !right || !p || !out_disp || !out_cost) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_params(p));
     SHP_TRY(check_image_dims(H, W));
     if (dmax <= 0) { set_error("dmax must be a positive integer"); return STEREO_EINVAL; }
@@ -553,6 +566,7 @@ int stereo_compute_disparity_host(const void *left, const void *right, int dtype
 
 int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dtype, int H, int W, int dmax,
                               const StereoParams *p, int d_begin, int d_end, int32_t *out_disp, float *out_cost) {
+    if (!dsi || !guide || !p || !out_disp || !out_cost) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_params(p));
     SHP_TRY(check_image_dims(H, W));
     if (dmax <= 0) { set_error("dsi must have at least one disparity layer"); return STEREO_EINVAL; }
@@ -597,6 +611,7 @@ int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dty
 
 int stereo_guided_filter_host(const double *guide, const float *src, int H, int W, int radius, double eps,
                               float *out) {
+    if (!guide || !src || !out) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_image_dims(H, W));
     if (radius <= 0) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
     if (!(eps > 0)) { set_error("eps must be positive"); return STEREO_EINVAL; }
@@ -633,6 +648,7 @@ int stereo_guided_filter_host(const double *guide, const float *src, int H, int 
 
 int stereo_guided_prepare_host(const double *guide, int H, int W, int radius, double *mean_guide, double *mean_gg,
                                double *var_g) {
+    if (!guide || !mean_guide || !mean_gg || !var_g) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_image_dims(H, W));
     if (radius <= 0) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
     size_t n = (size_t)H * W;
@@ -649,6 +665,7 @@ int stereo_guided_prepare_host(const double *guide, int H, int W, int radius, do
 }
 
 int stereo_integral_image_host(const double *image, int H, int W, double *out) {
+    if (!image || !out) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_image_dims(H, W));
     size_t n = (size_t)H * W, ni = ((size_t)H + 1) * ((size_t)W + 1);
     DevBuf di, tmp, integ;
@@ -660,6 +677,7 @@ int stereo_integral_image_host(const double *image, int H, int W, double *out) {
 }
 
 int stereo_box_filter_mean_host(const double *image, int H, int W, int radius, double *out) {
+    if (!image || !out) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_image_dims(H, W));
     if (radius < 0) { set_error("radius must be a non-negative integer"); return STEREO_EINVAL; }
     size_t n = (size_t)H * W, ni = ((size_t)H + 1) * ((size_t)W + 1);
@@ -674,6 +692,7 @@ int stereo_box_filter_mean_host(const double *image, int H, int W, int radius, d
 
 int stereo_box_filter_mean_indexed_host(const double *image, int H, int W, const int32_t *y0, const int32_t *y1,
                                         const int32_t *x0, const int32_t *x1, const double *area, double *out) {
+    if (!image || !out) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_image_dims(H, W));
     for (int y = 0; y < H; ++y)
         if (y0[y] < 0 || y1[y] >= H || y0[y] > H) { set_error("row window out of range"); return STEREO_EINVAL; }
@@ -698,6 +717,7 @@ int stereo_box_filter_mean_indexed_host(const double *image, int H, int W, const
 }
 
 int stereo_median_filter_host(const float *image, int H, int W, int radius, int mode, float *out) {
+    if (!image || !out) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_image_dims(H, W));
     if (radius <= 0) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
     size_t n = (size_t)H * W;
@@ -721,6 +741,7 @@ int stereo_median_filter_host(const float *image, int H, int W, int radius, int 
 }
 
 int stereo_median_filter_u8_host(const uint8_t *image, int H, int W, int radius, float *out) {
+    if (!image || !out) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_image_dims(H, W));
     if (radius <= 0) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
     size_t n = (size_t)H * W;
@@ -750,14 +771,17 @@ static int gauss_like_host(const float *image, int H, int W, double sigma, float
     return STEREO_OK;
 }
 int stereo_gaussian_filter_host(const float *image, int H, int W, double sigma, float *out) {
+    if (!image || !out) { set_error("null pointer"); return STEREO_EINVAL; }
     return gauss_like_host(image, H, W, sigma, out, false);
 }
 int stereo_bilateral_filter_host(const float *image, int H, int W, double sigma, float *out) {
+    if (!image || !out) { set_error("null pointer"); return STEREO_EINVAL; }
     return gauss_like_host(image, H, W, sigma, out, true);
 }
 
 int stereo_to_gray_host(const void *image, int dtype, int H, int W, int channels, int normalize, double scale,
                         float *out_gray) {
+    if (!image || !out_gray) { set_error("null pointer"); return STEREO_EINVAL; }
     if (H < 0 || W < 0) { set_error("negative image size"); return STEREO_EINVAL; }
     if (channels != 1 && channels < 3) { set_error("unsupported image shape"); return STEREO_EINVAL; }
     if (normalize && !(scale > 0)) { set_error("max_value must be positive"); return STEREO_EINVAL; }
@@ -774,6 +798,7 @@ int stereo_to_gray_host(const void *image, int dtype, int H, int W, int channels
 }
 
 int stereo_nan_minmax_host(const float *values, size_t n, float *out_min, float *out_max) {
+    if ((n && !values) || !out_min || !out_max) { set_error("null pointer"); return STEREO_EINVAL; }
     DevBuf dv, mm;
     SHP_TRY(dv.alloc(n * 4)); SHP_TRY(mm.alloc(8));
     if (n) SHP_HIP(hipMemcpy(dv.p, values, n * 4, hipMemcpyHostToDevice));
@@ -787,6 +812,7 @@ int stereo_nan_minmax_host(const float *values, size_t n, float *out_min, float 
 
 int stereo_pbm_rms_host(const int32_t *disparity, const float *ground_truth, const uint8_t *mask, int H, int W,
                         double bad_threshold, double *out) {
+    if (!disparity || !ground_truth || !mask || !out) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_image_dims(H, W));
     if (!(bad_threshold > 0)) { set_error("bad_threshold must be positive"); return STEREO_EINVAL; }
     size_t n = (size_t)H * W;

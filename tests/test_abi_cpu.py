@@ -74,3 +74,88 @@ def test_no_cpu_fallback_without_a_gpu():
     img = np.zeros((16, 16), dtype=np.float32)
     with pytest.raises(RuntimeError, match="no HIP device"):
         census.compute_wct_cost_volume(img, img, 4)
+
+
+def test_null_pointers_are_rejected_before_any_device_work():
+    """Every pointer-taking entry point answers a NULL data pointer with STEREO_EINVAL (no crash, no kernel launched
+    on a bad address); checked without a GPU, so the rejection demonstrably precedes all device calls."""
+    import ctypes
+
+    import _native
+
+    lib = _native.lib()
+    p = _native.StereoParams(wct_radius=4, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=3,
+                             guided_eps=0.0154, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
+    E = _native.EINVAL
+    N = None
+    assert lib.stereo_compute_disparity_dev(N, N, 8, 8, 4, p, 0, 4, N, 0, N, N) == E
+    assert lib.stereo_compute_disparity_dev(N, N, 8, 8, 4, None, 0, 4, N, 0, N, N) == E
+    assert lib.stereo_compute_disparity_progress_dev(N, N, 8, 8, 4, p, 0, 4, N, 0, N, 1, N, 1, N) == E
+    assert lib.stereo_wait_progress_dev(N, 0, 1, N) == E
+    assert lib.stereo_progress_plan(8, 8, None, 1, N, None) == E
+    assert lib.stereo_merge_keys_dev(N, N, 4, N) == E
+    assert lib.stereo_merge_key_slices_dev(N, 4, 2, N) == E
+    assert lib.stereo_keys_to_i64_dev(N, N, 4, N) == E
+    assert lib.stereo_keys_from_i64_dev(N, N, 4, N) == E
+    assert lib.stereo_unpack_keys_dev(N, 4, N, N, N) == E
+    assert lib.stereo_fused_workspace_bytes(8, 8, p, None) == E
+    assert lib.stereo_compute_disparity_host(N, N, _native.DT_F32, 8, 8, 4, p, 0, 4, N, N) == E
+    assert lib.stereo_aggregate_wta_host(N, N, _native.DT_F32, 8, 8, 4, p, 0, 4, N, N) == E
+    assert lib.stereo_wct_cost_volume_host(N, N, _native.DT_F32, 8, 8, 4, 4, 8.0, N) == E
+    assert lib.stereo_integral_image_host(N, 8, 8, N) == E
+    assert lib.stereo_box_filter_mean_host(N, 8, 8, 2, N) == E
+    assert lib.stereo_box_filter_mean_indexed_host(N, 8, 8, N, N, N, N, N, N) == E
+    assert lib.stereo_guided_prepare_host(N, 8, 8, 2, N, N, N) == E
+    assert lib.stereo_guided_filter_host(N, N, 8, 8, 2, 0.01, N) == E
+    assert lib.stereo_median_filter_host(N, 8, 8, 1, 0, N) == E
+    assert lib.stereo_median_filter_u8_host(N, 8, 8, 1, N) == E
+    assert lib.stereo_gaussian_filter_host(N, 8, 8, 1.0, N) == E
+    assert lib.stereo_bilateral_filter_host(N, 8, 8, 1.0, N) == E
+    assert lib.stereo_to_gray_host(N, _native.DT_U8, 8, 8, 3, 1, 255.0, N) == E
+    assert lib.stereo_nan_minmax_host(N, 4, None, None) == E
+    assert lib.stereo_pbm_rms_host(N, N, N, 8, 8, 1.0, N) == E
+    assert lib.stereo_generate_offsets(4, N) == E
+    assert lib.stereo_compute_weights(N, 32, 8.0, N) == E
+    assert lib.stereo_large_value(4, 8.0, None) == E
+    assert lib.stereo_hip_device_count(None) == E
+    assert "null" in _native.last_error().lower()
+
+
+def test_bad_arguments_are_rejected_before_any_device_work():
+    """Argument checks of the device entry points run before the first HIP call: without a GPU they still answer
+    STEREO_EINVAL (a call that reached the device layer would answer STEREO_EHIP here)."""
+    import ctypes
+
+    import _native
+
+    lib = _native.lib()
+    p = _native.StereoParams(wct_radius=4, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=3,
+                             guided_eps=0.0154, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
+    fake = ctypes.create_string_buffer(64)   # never dereferenced by a call that is rejected
+    ptr = ctypes.cast(fake, ctypes.c_void_p)
+    nbytes = ctypes.c_size_t(0)
+    _native.check(lib.stereo_fused_workspace_bytes(40, 60, p, ctypes.byref(nbytes)))
+
+    def call(h=40, w=60, dmax=8, params=p, d0=0, d1=8, ws_bytes=None):
+        return lib.stereo_compute_disparity_dev(ptr, ptr, h, w, dmax, params, d0, d1, ptr,
+                                                nbytes.value if ws_bytes is None else ws_bytes, ptr, None)
+
+    E = _native.EINVAL
+    assert call(ws_bytes=nbytes.value - 1) == E
+    assert call(d0=5, d1=4) == E and call(d1=9) == E and call(d0=-1) == E
+    assert call(dmax=0, d1=0) == E
+    assert call(h=0) == E and call(w=-3) == E
+    bad_r = _native.StereoParams(wct_radius=9, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=3,
+                                 guided_eps=0.0154, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
+    assert call(params=bad_r) == _native.EUNSUPPORTED   # census radius above 8: no packed word layout
+    bad_eps = _native.StereoParams(wct_radius=4, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=3,
+                                   guided_eps=0.0, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
+    assert call(params=bad_eps) == E
+    row_end = (ctypes.c_int32 * 16)()
+    n = ctypes.c_int(0)
+    assert lib.stereo_progress_plan(40, 60, p, 0, row_end, ctypes.byref(n)) == E
+    assert lib.stereo_progress_plan(40, 60, p, 17, row_end, ctypes.byref(n)) == E
+    assert lib.stereo_progress_plan(40, 60, p, 4, row_end, ctypes.byref(n)) == _native.OK and n.value >= 1
+    assert lib.stereo_compute_disparity_progress_dev(ptr, ptr, 40, 60, 8, p, 0, 8, ptr, nbytes.value, ptr, 0, ptr, 1, None) == E
+    assert lib.stereo_compute_disparity_progress_dev(ptr, ptr, 40, 60, 8, p, 0, 8, ptr, nbytes.value, ptr, 3, ptr, 1, None) == E
+    assert lib.stereo_wait_progress_dev(ptr, 16, 1, None) == E

@@ -111,3 +111,46 @@ def test_merge_key_slices_is_the_unsigned_min():
     torch.cuda.synchronize()
     got = t.cpu().numpy().view(np.uint64)
     assert np.array_equal(got[:chunk], want) and np.array_equal(got[chunk:], raw[chunk:])
+
+
+def test_device_entry_points_reject_bad_arguments():
+    """stereo_compute_disparity_dev / stereo_fused_workspace_bytes: status codes, nothing launched on bad input."""
+    import torch
+
+    import _native
+
+    lib = _native.lib()
+    dev = torch.device("cuda", 0)
+    h, w, dmax = 40, 60, 8
+    img = torch.rand(h * w, dtype=torch.float32, device=dev)
+    params = _params(_native)
+    nbytes = ctypes.c_size_t(0)
+    _native.check(lib.stereo_fused_workspace_bytes(h, w, params, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    keys = torch.empty(h * w, dtype=torch.int64, device=dev)
+
+    def call(hh=h, ww=w, dd=dmax, p=params, d0=0, d1=dmax, ws_bytes=nbytes.value, left=img.data_ptr()):
+        return lib.stereo_compute_disparity_dev(left, img.data_ptr(), hh, ww, dd, p, d0, d1, ws.data_ptr(), ws_bytes,
+                                                keys.data_ptr(), None)
+
+    assert call() == _native.OK
+    assert call(ws_bytes=nbytes.value - 1) == _native.EINVAL and "workspace" in _native.last_error()
+    assert call(d0=5, d1=4) == _native.EINVAL
+    assert call(d1=dmax + 1) == _native.EINVAL
+    assert call(dd=0, d1=0) == _native.EINVAL
+    assert call(hh=0) == _native.EINVAL
+    assert call(left=None) == _native.EINVAL
+    big_r = _native.StereoParams(wct_radius=4, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=7,
+                                 guided_eps=0.0154, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
+    assert call(p=big_r) == _native.EUNSUPPORTED
+    bad_r = _native.StereoParams(wct_radius=9, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=3,
+                                 guided_eps=0.0154, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
+    assert call(p=bad_r) in (_native.EINVAL, _native.EUNSUPPORTED)
+    assert lib.stereo_fused_workspace_bytes(h, w, params, None) == _native.EINVAL
+    # an empty disparity range is legal: every key stays (+inf, 0)
+    assert call(d0=3, d1=3) == _native.OK
+    disp = torch.empty(h * w, dtype=torch.int32, device=dev)
+    cost = torch.empty(h * w, dtype=torch.float32, device=dev)
+    _native.check(lib.stereo_unpack_keys_dev(keys.data_ptr(), h * w, disp.data_ptr(), cost.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert int(disp.abs().sum()) == 0 and bool(torch.isinf(cost).all())
