@@ -175,6 +175,11 @@ int stereo_compute_disparity_progress_dev(const float *d_left, const float *d_ri
                                           uint32_t *d_progress, uint32_t epoch, void *stream);
 int stereo_wait_progress_dev(const uint32_t *d_progress, int band, uint32_t epoch, void *stream);
 
+/* The host entry points keep the device buffers they allocate in a per-process cache (at most 8 GiB
+ * idle) so that a caller processing frame after frame does not pay hipMalloc / hipFree per call;
+ * no counterpart in the reference.  This returns every cached buffer to the driver. */
+int stereo_hip_release_cache(void);
+
 /* Test hook, no counterpart in the reference: selects the fused guided kernel compute_disparity
  * uses, so the variants can be compared on the same input.  0 = the best one that applies
  * (default), 1 = the general kernel (float64 sums exchanged through LDS), 2 = the fast kernel

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "stereo_nan_minmax_host": [_VP, _SZ, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)],
     "stereo_pbm_rms_host": [_VP, _VP, _VP, _I, _I, _D, _VP],
     "stereo_debug_force_general_kernel": [_I],
+    "stereo_hip_release_cache": [],
     "stereo_profile_begin": [_I],
     "stereo_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
 }

@@ -36,6 +36,78 @@ static ProfileState g_prof;
 // debugging/testing: 0 = best kernel, 1 = general fused kernel, 2 = fast kernel with one column per lane
 static int g_force_kernel = 0;
 
+// ---- cache of device buffers ---------------------------------------------------------------------
+namespace {
+struct PoolEntry { void *p; size_t capacity; int device; };
+std::mutex g_pool_mutex;
+std::vector<PoolEntry> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_MAX_BYTES = (size_t)8 << 30;   // cached (idle) bytes kept per process
+}  // namespace
+
+void *pool_alloc(size_t bytes, size_t *capacity) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        int best = -1;
+        for (int i = 0; i < (int)g_pool.size(); ++i) {
+            const PoolEntry &e = g_pool[i];
+            // a cached buffer serves a request it is not much too large for
+            if (e.device == dev && e.capacity >= bytes && e.capacity <= bytes + bytes / 4 + (1u << 20) &&
+                (best < 0 || e.capacity < g_pool[best].capacity))
+                best = i;
+        }
+        if (best >= 0) {
+            PoolEntry e = g_pool[best];
+            g_pool.erase(g_pool.begin() + best);
+            g_pool_bytes -= e.capacity;
+            *capacity = e.capacity;
+            return e.p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t err = hipMalloc(&p, bytes);
+    if (err != hipSuccess) {
+        // memory held by the cache may be what is missing
+        (void)hipGetLastError();
+        pool_release_all();
+        err = hipMalloc(&p, bytes);
+    }
+    if (err != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(err));
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    *capacity = bytes;
+    return p;
+}
+
+void pool_free(void *p, size_t capacity) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        if (g_pool_bytes + capacity <= POOL_MAX_BYTES && g_pool.size() < 64) {
+            g_pool.push_back(PoolEntry{p, capacity, dev});
+            g_pool_bytes += capacity;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+void pool_release_all() {
+    std::vector<PoolEntry> drop;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        drop.swap(g_pool);
+        g_pool_bytes = 0;
+    }
+    for (const PoolEntry &e : drop) (void)hipFree(e.p);
+}
+
+
 static int check_params(const StereoParams *p) {
     if (!p) { set_error("params is NULL"); return STEREO_EINVAL; }
     switch (p->filter_kind) {
@@ -439,6 +511,11 @@ int stereo_compute_disparity_progress_dev(const float *d_left, const float *d_ri
 int stereo_wait_progress_dev(const uint32_t *d_progress, int band, uint32_t epoch, void *stream) {
     if (!d_progress) { set_error("null pointer"); return STEREO_EINVAL; }
     return launch_progress_wait(d_progress, band, epoch, static_cast<hipStream_t>(stream));
+}
+
+int stereo_hip_release_cache(void) {
+    pool_release_all();
+    return STEREO_OK;
 }
 
 int stereo_debug_force_general_kernel(int on) {

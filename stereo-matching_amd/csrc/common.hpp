@@ -33,9 +33,17 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 #define SHP_LAUNCH_CHECK() SHP_HIP(hipGetLastError())
 
 // ---- RAII device buffer (host-pointer entry points only) -----------------------------------
+// Device allocations of the host entry points come from a small per-process cache: a frame-sized
+// hipMalloc / hipFree pair costs about as much as a kernel, and a caller that processes frame after
+// frame asks for the same sizes again and again.  stereo_hip_release_cache() returns everything.
+void *pool_alloc(size_t bytes, size_t *capacity);   // nullptr on failure (error text set)
+void pool_free(void *p, size_t capacity);
+void pool_release_all();
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    size_t capacity = 0;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -43,20 +51,16 @@ struct DevBuf {
     int alloc(size_t n) {
         release();
         if (n == 0) n = 1;
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
-            (void)hipGetLastError();
-            return STEREO_ENOMEM;
-        }
+        p = pool_alloc(n, &capacity);
+        if (!p) return STEREO_ENOMEM;
         bytes = n;
         return STEREO_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p, capacity);
         p = nullptr;
         bytes = 0;
+        capacity = 0;
     }
     template <class T>
     T *as() const { return static_cast<T *>(p); }
