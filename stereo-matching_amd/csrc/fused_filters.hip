@@ -16,6 +16,12 @@
 
 #include "census_dev.hpp"
 
+// The reference rescales a median with separate float32 multiply and add (filters.py:177-180), the
+// quantisation is a subtract followed by a multiply, and the bilateral filter divides two float32
+// sums: a fused multiply-add anywhere in these chains changes the last bit of some outputs.  Fused
+// operations in this file are written out (fmaf) where they are wanted.
+#pragma clang fp contract(off)
+
 namespace shp {
 
 constexpr int FF_TW = 64, FF_TH = 16, FF_THREADS = 256, FF_ROWS_PER_THREAD = 4;
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             const int idx = tid + j * FF_THREADS;
             float c = ff_cost<WordT>(rw, a.cfg, lword[j], lvalid[j], ro[j], gxs[j], d);
             if (MEDIAN) {
-                float s = __fmul_rn(__fsub_rn(c, qlo), qscale);
+                float s = (c - qlo) * qscale;
                 s = fminf(fmaxf(s, 0.f), 255.f);
                 const uint32_t b = flat ? 0u : (uint32_t)rintf(s);
                 mylo = min(mylo, b);   // (a thread's surplus slot repeats a tile pixel)
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) outv[j] = (wsum[j] <= 0.f) ? c[j] : __fdiv_rn(vsum[j], wsum[j]);
+            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) outv[j] = (wsum[j] <= 0.f) ? c[j] : vsum[j] / wsum[j];
         } else {
             // the bytes of this tile (halo included) lie in [tlo, thi]: so do all its medians.  Cost
             // layers mostly hold a narrow band of levels (plus 255 where a cost is `large`).
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < FF_ROWS_PER_THREAD; ++j)
-                outv[j] = flat ? qlo : __fadd_rn(__fmul_rn((float)med[j], qinv), qlo);
+                outv[j] = flat ? qlo : (float)med[j] * qinv + qlo;   // two roundings (contraction is off in this file)
         }
 #pragma unroll
         for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
