@@ -203,12 +203,21 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         if (slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
         const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();
         if (prof) SHP_HIP(hipEventRecord(g_prof.start[g_prof.used], s));
+        // eps is judged against the guide's range on the device (the range is only known there): a fast kernel
+        // runs iff eps >= FAST_KERNEL_MIN_EPS * max(1, max|guide|^2); the general kernel is enqueued behind it
+        // with the opposite test, so exactly one of the two does the frame and the call stays asynchronous.
+        // A forced kernel (test hook) runs unconditionally.
+        const float gate_eps = (float)p->guided_eps;
+        const float gate_min = g_force_kernel == 0 ? (float)FAST_KERNEL_MIN_EPS : 0.f;
         int rc = pair ? launch_fused_guided_pair(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius,
-                                                 d_begin, d_end, slices, d_keys, d_q_out, s, progress)
+                                                 d_begin, d_end, slices, d_keys, d_q_out, s, progress, gate_eps, gate_min)
                  : fast ? launch_fused_guided_fast(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius,
-                                                 d_begin, d_end, slices, d_keys, d_q_out, s)
+                                                 d_begin, d_end, slices, d_keys, d_q_out, s, gate_eps, gate_min)
                       : launch_fused_guided(lw, rw, &cfg, nullptr, d_left, STEREO_DT_F32, mean, invden, H, W, dmax,
                                             p->guided_radius, d_begin, d_end, d_keys, d_q_out, 0, s);
+        if (rc == STEREO_OK && (pair || fast) && gate_min > 0.f)
+            rc = launch_fused_guided(lw, rw, &cfg, nullptr, d_left, STEREO_DT_F32, mean, invden, H, W, dmax,
+                                     p->guided_radius, d_begin, d_end, d_keys, d_q_out, 0, s, gmax, gate_eps, gate_min);
         if (prof) {
             SHP_HIP(hipEventRecord(g_prof.stop[g_prof.used], s));
             ++g_prof.used;

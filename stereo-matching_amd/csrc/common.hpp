@@ -131,7 +131,8 @@ bool fused_guided_supported(int guided_radius);
 int launch_fused_guided(const void *d_lw, const void *d_rw, const CensusCfg *cfg, const float *d_dsi,
                         const void *d_guide, int guide_dtype, const double *d_mean, const double *d_invden,
                         int H, int W, int dmax, int guided_radius, int d_begin, int d_end, uint64_t *d_keys,
-                        float *d_q_out, int atomic_out, hipStream_t s);
+                        float *d_q_out, int atomic_out, hipStream_t s,
+                        const float *gate_gmax = nullptr, float gate_eps = 0.f, float gate_min = 0.f);
 
 
 // fast fused kernel (guided_fast.hip): exact census weights, float32 guide, guided radius <= 4
@@ -148,7 +149,8 @@ int pair_tile_height(int guided_radius, bool word64);
 int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
-                             float *d_q_out, hipStream_t s, const BandProgress *progress = nullptr);
+                             float *d_q_out, hipStream_t s, const BandProgress *progress = nullptr,
+                             float gate_eps = 0.f, float gate_min = 0.f);
 int launch_progress_finish(uint32_t *words, int n_bands, uint32_t epoch, hipStream_t s);
 int launch_progress_wait(const uint32_t *words, int band, uint32_t epoch, hipStream_t s);
 bool fused_fast_supported(const CensusCfg &cfg, int guided_radius);
@@ -156,7 +158,7 @@ int fused_fast_slices(int H, int W, int guided_radius, int n_disp);
 int launch_fused_guided_fast(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
-                             float *d_q_out, hipStream_t s);
+                             float *d_q_out, hipStream_t s, float gate_eps = 0.f, float gate_min = 0.f);
 
 // volume-free median (uint8-quantised) / Gaussian / bilateral compute_disparity (fused_filters.hip)
 bool fused_filter_supported(int filter_kind, int radius);

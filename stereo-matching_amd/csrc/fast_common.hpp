@@ -28,7 +28,15 @@ struct FastArgs {
     uint32_t *progress;
     int band_tile_rows;     // tile rows per band
     uint32_t epoch;
+    // The float32 second stage is accurate to 1e-5 of a cost unit only while eps is not too small
+    // against the guide's range: the kernel runs iff eps >= gate_min * max(1, gmax^2) and leaves the
+    // frame to the float64 kernel (launched behind it with the opposite test) otherwise.  0: no test.
+    float gate_eps, gate_min;
 };
+
+__device__ __forceinline__ bool eps_gate_takes_fast(float eps, float gate_min, float gmax) {
+    return eps >= gate_min * fmaxf(1.f, gmax * gmax);
+}
 
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138

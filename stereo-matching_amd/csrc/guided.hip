@@ -144,6 +144,9 @@ struct FusedArgs {
     int H, W, D;
     int d_begin, d_end;
     int atomic_out;        // 1: merge into keys with atomicMin, 0: plain store
+    // set when a fast kernel was launched ahead with the opposite test: run only if it declined
+    const float *gate_gmax;
+    float gate_eps, gate_min;
 };
 
 // wavefront-local ordering of LDS traffic: lanes exchange values through LDS without a
@@ -166,6 +169,10 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_kernel(FusedArgs a) {
     using PT = typename std::conditional<INT_UNITS, uint32_t, double>::type;  // cost sums
     static_assert(SRC != SRC_DSI || !INT_UNITS, "a materialised volume holds arbitrary floats");
 
+    if (a.gate_gmax) {
+        const float g = *a.gate_gmax;
+        if (a.gate_eps >= a.gate_min * fmaxf(1.f, g * g)) return;   // the fast kernel took the frame
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // carve (all offsets multiples of 16)
     unsigned char *sp = smem_raw;
@@ -377,10 +384,12 @@ bool fused_guided_supported(int guided_radius) { return guided_radius >= 1 && gu
 int launch_fused_guided(const void *d_lw, const void *d_rw, const CensusCfg *cfg, const float *d_dsi,
                         const void *d_guide, int guide_dtype, const double *d_mean, const double *d_invden,
                         int H, int W, int dmax, int guided_radius, int d_begin, int d_end, uint64_t *d_keys,
-                        float *d_q_out, int atomic_out, hipStream_t s) {
+                        float *d_q_out, int atomic_out, hipStream_t s, const float *gate_gmax, float gate_eps,
+                        float gate_min) {
     if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
     FusedArgs a;
     memset(&a, 0, sizeof(a));
+    a.gate_gmax = gate_gmax; a.gate_eps = gate_eps; a.gate_min = gate_min;
     a.lw = d_lw; a.rw = d_rw; a.dsi = d_dsi; a.guide = d_guide; a.mean = d_mean; a.invden = d_invden;
     a.keys = d_keys; a.q_out = d_q_out;
     if (cfg) a.cfg = *cfg;

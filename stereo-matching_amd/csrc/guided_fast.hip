@@ -223,6 +223,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     static_assert(NI % WIN == 0, "the row loop is unrolled by the window length without a tail");
     using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
 
+    if (a.gate_min > 0.f && !eps_gate_takes_fast(a.gate_eps, a.gate_min, *a.gmax)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char *sp = smem_raw;
     TileLds<WordT> t;
@@ -405,10 +406,11 @@ int fused_fast_slices(int H, int W, int guided_radius, int n_disp) {
 int launch_fused_guided_fast(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
-                             float *d_q_out, hipStream_t s) {
+                             float *d_q_out, hipStream_t s, float gate_eps, float gate_min) {
     if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
     FastArgs a;
     memset(&a, 0, sizeof(a));
+    a.gate_eps = gate_eps; a.gate_min = gate_min;
     a.lw = d_lw; a.rw = d_rw; a.guide = d_guide; a.mean = d_mean; a.invden = d_invden; a.gmax = d_gmax;
     a.keys = d_keys; a.q_out = d_q_out;
     a.H = H; a.W = W; a.D = dmax; a.d_begin = d_begin; a.d_end = d_end;

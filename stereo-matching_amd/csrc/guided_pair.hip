@@ -364,6 +364,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
     t.next_d = reinterpret_cast<int *>(sp); sp += 16;
     t.k = reinterpret_cast<short *>(sp);
 
+    if (a.gate_min > 0.f && !eps_gate_takes_fast(a.gate_eps, a.gate_min, *a.gmax)) return;
     const int lane = threadIdx.x & 63;
     const int H = a.H, W = a.W;
     const int tx0 = blockIdx.x * TWV, ty0 = blockIdx.y * TH;
@@ -575,7 +576,8 @@ int fused_pair_slices(int H, int W, int guided_radius, bool word64, int n_disp) 
 int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
-                             float *d_q_out, hipStream_t s, const BandProgress *progress) {
+                             float *d_q_out, hipStream_t s, const BandProgress *progress, float gate_eps,
+                             float gate_min) {
     if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
     FastArgs a;
     memset(&a, 0, sizeof(a));
@@ -586,6 +588,7 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
     a.radius = cfg.radius; a.unit = cfg.unit;
     a.large_units = (uint32_t)std::lround((double)cfg.large / (double)cfg.unit);
     a.atomic_out = a.n_slices > 1;
+    a.gate_eps = gate_eps; a.gate_min = gate_min;
     if (progress && progress->band_tile_rows > 0) {
         a.progress = progress->words;
         a.band_tile_rows = progress->band_tile_rows;

@@ -55,17 +55,22 @@ def run_cases(n_cases: int, seed: int, verbose: bool = True) -> int:
         d_begin = 0 if rng.random() < 0.6 else int(rng.integers(0, dmax))
         d_end = dmax if rng.random() < 0.6 else int(rng.integers(d_begin, dmax + 1))
         left, right, _ = synth_pair_gray(h, w, dmax, seed=1000 + case)
-        tag = f"case {case}: {w}x{h} dmax {dmax} d[{d_begin},{d_end}) census r {wct} {filt} {kw}"
+        base = 8.0
+        if seed >= 100:  # (the batches pinned in the test-suite keep their historical draw sequence)
+            base = float(rng.choice([8.0, 8.0, 8.0, 16.0, 1.0, 3.3, 0.7]))
+            if rng.random() < 0.15:
+                left, right = (left * 255).astype(np.uint8), (right * 255).astype(np.uint8)
+        tag = f"case {case}: {w}x{h} dmax {dmax} d[{d_begin},{d_end}) census r {wct} base {base} {left.dtype} {filt} {kw}"
         try:
-            dsi = orc.wct_cost_volume(left, right, dmax, radius=wct)
+            dsi = orc.wct_cost_volume(left, right, dmax, radius=wct, base_weight=base)
             sub = np.ascontiguousarray(dsi[:, :, d_begin:d_end])
             if d_end > d_begin:
                 dref, cref, layers = orc.aggregate_and_wta(sub, left, okind, oradius, oparam, want_layers=True)
                 dref = dref + np.where(np.isfinite(cref), d_begin, 0).astype(np.int32)
             else:
                 dref, cref, layers = np.zeros((h, w), np.int32), np.full((h, w), np.inf, np.float32), None
-            d, c = stereo.compute_disparity(left, right, dmax, wct_radius=wct, filter_type=filt, show_progress=False,
-                                            d_begin=d_begin, d_end=d_end, **kw)
+            d, c = stereo.compute_disparity(left, right, dmax, wct_radius=wct, base_weight=base, filter_type=filt,
+                                            show_progress=False, d_begin=d_begin, d_end=d_end, **kw)
             fin = np.isfinite(cref)
             problems = []
             if not np.array_equal(np.isfinite(c), fin):

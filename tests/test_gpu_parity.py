@@ -614,3 +614,22 @@ def test_fused_median_rescale_rounds_twice(oracle):
     d, c = stereo.compute_disparity(left, right, dmax, wct_radius=8, filter_type="median", median_radius=1,
                                     show_progress=False, d_begin=d0, d_end=d1)
     assert np.array_equal(d, dref) and np.array_equal(c, cref)
+
+
+def test_guided_eps_is_judged_against_the_guide_range(oracle):
+    """A uint8 image as guide (values 0..255 instead of 0..1) makes eps = 0.005 tiny against the guide's variance:
+    the float32 second stage of the fast kernels would be off by 5e-5 of a cost unit here.  The choice between the
+    fast and the float64 kernel is made on the device from eps / max|guide|^2 (found by fuzzing)."""
+    import stereo
+    from synth import synth_pair_gray
+    h, w, dmax = 100, 191, 3
+    left, right, _ = synth_pair_gray(h, w, dmax, seed=2252)
+    left, right = (left * 255).astype(np.uint8), (right * 255).astype(np.uint8)
+    dsi = oracle.wct_cost_volume(left, right, dmax, radius=4)
+    dref, cref, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, 4, 0.005, want_layers=True)
+    d, c = stereo.compute_disparity(left, right, dmax, guided_radius=4, guided_eps=0.005, show_progress=False)
+    fin = np.isfinite(cref)
+    assert np.array_equal(np.isfinite(c), fin)
+    assert rel_err(c[fin], cref[fin]) <= 1e-5
+    for y, x in np.argwhere(d != dref):
+        assert abs(float(layers[d[y, x], y, x]) - float(cref[y, x])) <= 1e-5 * max(1.0, abs(float(cref[y, x])))
