@@ -93,6 +93,9 @@ def run_cases(n_cases: int, seed: int, verbose: bool = True) -> int:
                 filt = str(rng.choice(["guided", "median", "gaussian", "bilateral"]))
                 left, right, _ = synth_pair_gray(max(h, 4), max(w, 4), dmax, seed=case)
                 dsi = orc.wct_cost_volume(left, right, dmax)
+                if rng.random() < 0.5:   # a volume that is not a census cost: arbitrary floats, many ties
+                    dsi = (np.round(rng.random(dsi.shape) * 400.0) / 4.0).astype(np.float32)
+                    tag += " random-volume"
                 kind = {"guided": orc.FILTER_GUIDED, "median": orc.FILTER_MEDIAN_U8Q, "gaussian": orc.FILTER_GAUSSIAN,
                         "bilateral": orc.FILTER_BILATERAL}[filt]
                 radius = 3 if filt in ("guided", "median") else 0

@@ -58,8 +58,16 @@ def run_cases(n_cases: int, seed: int, verbose: bool = True) -> int:
         base = 8.0
         if seed >= 100:  # (the batches pinned in the test-suite keep their historical draw sequence)
             base = float(rng.choice([8.0, 8.0, 8.0, 16.0, 1.0, 3.3, 0.7]))
-            if rng.random() < 0.15:
+            u = rng.random()
+            if u < 0.15:
                 left, right = (left * 255).astype(np.uint8), (right * 255).astype(np.uint8)
+            elif u < 0.35:   # another brightness scale: the census is unchanged, the guide is not
+                sc = np.float32(rng.choice([255.0, 1.0 / 255.0, 4096.0, 1e-3, 3.0]))
+                left, right = left * sc, right * sc
+            elif u < 0.42:
+                left, right = left.astype(np.float64), right.astype(np.float64)
+            elif u < 0.45:
+                left = np.full_like(left, 0.25)
         tag = f"case {case}: {w}x{h} dmax {dmax} d[{d_begin},{d_end}) census r {wct} base {base} {left.dtype} {filt} {kw}"
         try:
             dsi = orc.wct_cost_volume(left, right, dmax, radius=wct, base_weight=base)
