@@ -154,3 +154,47 @@ def test_device_entry_points_reject_bad_arguments():
     _native.check(lib.stereo_unpack_keys_dev(keys.data_ptr(), h * w, disp.data_ptr(), cost.data_ptr(), None))
     torch.cuda.synchronize()
     assert int(disp.abs().sum()) == 0 and bool(torch.isinf(cost).all())
+
+
+def test_progress_reporting_random_shapes():
+    """Random frame shapes, band counts, disparity ranges and filters: the reporting entry point writes the same keys
+    as the plain one and publishes every band flag."""
+    import torch
+
+    import _native
+    from synth import synth_pair_gray
+
+    lib = _native.lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(99)
+    main = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for case in range(40):
+        h, w, dmax = int(rng.integers(1, 260)), int(rng.integers(1, 400)), int(rng.integers(1, 70))
+        filt = str(rng.choice(["guided", "guided", "median", "gaussian"]))
+        bands = int(rng.integers(1, 17))
+        d0 = int(rng.integers(0, dmax))
+        d1 = int(rng.integers(d0, dmax + 1))
+        left_np, right_np, _ = synth_pair_gray(h, w, dmax, seed=case)
+        left, right = torch.from_numpy(left_np).to(dev), torch.from_numpy(right_np).to(dev)
+        params = _params(_native, filt, wct_radius=int(rng.choice([4, 8])))
+        nbytes = ctypes.c_size_t(0)
+        _native.check(lib.stereo_fused_workspace_bytes(h, w, params, ctypes.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        plain = torch.empty(h * w, dtype=torch.int64, device=dev)
+        keys = torch.zeros(h * w, dtype=torch.int64, device=dev)
+        _native.check(lib.stereo_compute_disparity_dev(left.data_ptr(), right.data_ptr(), h, w, dmax, params, d0, d1,
+                                                       ws.data_ptr(), nbytes.value, plain.data_ptr(), main))
+        row_end = (ctypes.c_int32 * 16)()
+        n_bands = ctypes.c_int(0)
+        _native.check(lib.stereo_progress_plan(h, w, params, bands, row_end, ctypes.byref(n_bands)))
+        progress = torch.zeros(48, dtype=torch.int32, device=dev)
+        _native.check(lib.stereo_compute_disparity_progress_dev(
+            left.data_ptr(), right.data_ptr(), h, w, dmax, params, d0, d1, ws.data_ptr(), nbytes.value, keys.data_ptr(),
+            n_bands.value, progress.data_ptr(), 7, main))
+        for b in range(n_bands.value):
+            _native.check(lib.stereo_wait_progress_dev(progress.data_ptr(), b, 7, main))
+        torch.cuda.synchronize()
+        words = progress.cpu().numpy()
+        tag = f"case {case}: {w}x{h} dmax {dmax} d[{d0},{d1}) {filt} bands {bands}->{n_bands.value}"
+        assert list(words[16:16 + n_bands.value]) == [7] * n_bands.value and not words[32:48].any(), tag
+        assert torch.equal(keys, plain), tag
