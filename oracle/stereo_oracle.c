@@ -440,6 +440,10 @@ int orc_median_filter(const float *image, int height, int width, int radius, flo
                 int yy = clampi(y + dy, 0, height - 1);
                 for (int dx = -radius; dx <= radius; ++dx) win[k++] = image[(size_t)yy * width + clampi(x + dx, 0, width - 1)];
             }
+            /* np.median (filters.py:105,124) returns NaN for a window that holds a NaN */
+            int has_nan = 0;
+            for (int i = 0; i < cnt; ++i) has_nan |= isnan(win[i]);
+            if (has_nan) { out[(size_t)y * width + x] = NAN; continue; }
             qsort(win, cnt, sizeof(float), cmp_f32);
             out[(size_t)y * width + x] = win[cnt / 2];
         }

@@ -721,14 +721,19 @@ int stereo_guided_filter_host(const double *guide, const float *src, int H, int 
         SHP_TRY(layered_guided_apply(ds.as<float>(), H, W, radius, eps, ws.p, q.as<float>(), nullptr));
     }
     SHP_HIP(hipMemcpy(out, q.p, n * 4, hipMemcpyDeviceToHost));
-    if (gmax.p) {
-        bool finite = true;
-        SHP_TRY(guide_is_finite(gmax.p, &finite));
-        if (!finite)
-            poison_like_reference(guide, H, W, radius, [&](int y, int x0) {
-                for (int x = x0; x < W; ++x) out[(size_t)y * W + x] = NAN;
-            });
-    }
+    // A NaN or infinite pixel of the guide or of the source reaches, through the reference's integral images,
+    // every output below and to the right of it (from 2 * radius rows / columns before it).
+    auto fill = [&](int y, int x0) {
+        for (int x = x0; x < W; ++x) out[(size_t)y * W + x] = NAN;
+    };
+    bool guide_finite = true;
+    if (gmax.p) SHP_TRY(guide_is_finite(gmax.p, &guide_finite));
+    else
+        for (size_t i = 0; i < n && guide_finite; ++i) guide_finite = std::fabs(guide[i]) <= 1.7976931348623157e308;
+    if (!guide_finite) poison_like_reference(guide, H, W, radius, fill);
+    bool src_finite = true;
+    for (size_t i = 0; i < n && src_finite; ++i) src_finite = std::fabs(src[i]) <= 3.402823466e38f;
+    if (!src_finite) poison_like_reference(src, H, W, radius, fill);
     return STEREO_OK;
 }
 

@@ -107,6 +107,14 @@ __global__ __launch_bounds__(256) void median_f32_kernel(const float *__restrict
     for (int ly = threadIdx.x >> 6; ly < FT_TH; ly += 4) {
         int gy = y0 + ly, gx = x0 + lx;
         if (gy >= H || gx >= W) continue;
+        // np.median (filters.py:105,124) returns NaN for a window that holds a NaN; the keys of NaNs lie
+        // above +inf's (0xff800000) or below -inf's (0x007fffff)
+        bool has_nan = false;
+        for (int dy = 0; dy < K; ++dy)
+            for (int dx = 0; dx < K; ++dx) {
+                const uint32_t k = tile[(ly + dy) * LW + lx + dx];
+                has_nan = has_nan || k > 0xff800000u || k < 0x007fffffu;
+            }
         uint32_t lo = 0u, hi = 0xffffffffu;  // invariant: count(<= hi) >= need
         while (lo < hi) {
             uint32_t mid = lo + ((hi - lo) >> 1);
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void median_f32_kernel(const float *__restrict
                 for (int dx = 0; dx < K; ++dx) cnt += (tile[(ly + dy) * LW + lx + dx] <= mid) ? 1 : 0;
             if (cnt >= need) hi = mid; else lo = mid + 1;
         }
-        out[(size_t)gy * W + gx] = ordered_to_f32(lo);
+        out[(size_t)gy * W + gx] = has_nan ? __int_as_float(0x7fc00000) : ordered_to_f32(lo);
     }
 }
 

@@ -20,3 +20,12 @@ def test_random_operator_cases_match_oracle(oracle, seed, capsys):
 
     failures = fuzz_ops_vs_oracle.run_cases(150, seed, verbose=False)
     assert failures == 0, capsys.readouterr().out
+
+
+def test_non_finite_pixels_through_the_operators(oracle, capsys):
+    """NaN / inf inputs of integral image, box mean, guided, Gaussian, bilateral and exact median filters: same
+    NaN / inf pattern as the oracle (see tests/fuzz_nonfinite_vs_oracle.py)."""
+    import fuzz_nonfinite_vs_oracle
+
+    failures = fuzz_nonfinite_vs_oracle.run_cases(300, 5)
+    assert failures == 0, capsys.readouterr().out
