@@ -263,6 +263,14 @@ static bool fused_path_applies(const StereoParams *p) {
     return fused_filter_supported(p->filter_kind, p->median_radius);
 }
 
+// sets *flag when some element is NaN or infinite
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float *__restrict__ v, size_t n, uint32_t *flag) {
+    bool bad = false;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        bad = bad || !(fabsf(v[i]) <= 3.402823466e38f);
+    if (bad) *flag = 1u;
+}
+
 // stereo.py:145-170 one layer at a time on a (D', H, W) device volume whose layer k is
 // disparity d_begin + k.  Used for every filter / parameter combination the fused kernels do
 // not cover.  Everything is enqueued on `s`; the only host sync is the final flag read.
@@ -669,7 +677,23 @@ int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dty
     SHP_TRY(keys.alloc(n * 8));
     SHP_HIP(hipMemcpy(ddsi.p, dsi, n * (size_t)dmax * 4, hipMemcpyHostToDevice));
     SHP_HIP(hipMemcpy(dg.p, guide, n * dtype_size(guide_dtype), hipMemcpyHostToDevice));
-    if (p->filter_kind == STEREO_FILTER_GUIDED && fused_guided_supported(p->guided_radius)) {
+    bool fused_guided = p->filter_kind == STEREO_FILTER_GUIDED && fused_guided_supported(p->guided_radius);
+    if (fused_guided) {
+        // The reference's integral images spread a NaN or infinite cost over the whole quadrant below and to the
+        // right of it, layer by layer; the fused kernel's window sums would keep it local.  Such a volume takes
+        // the layer-at-a-time path, whose box sums are integral images too.
+        DevBuf flag;
+        SHP_TRY(flag.alloc(4));
+        SHP_HIP(hipMemsetAsync(flag.p, 0, 4, nullptr));
+        const size_t nv = n * (size_t)dmax;
+        hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)std::min<size_t>((nv + 255) / 256, 8192)), dim3(256), 0,
+                           nullptr, ddsi.as<float>(), nv, flag.as<uint32_t>());
+        SHP_LAUNCH_CHECK();
+        uint32_t h = 0;
+        SHP_HIP(hipMemcpy(&h, flag.p, 4, hipMemcpyDeviceToHost));
+        if (h) fused_guided = false;
+    }
+    if (fused_guided) {
         SHP_TRY(mean.alloc(n * 8)); SHP_TRY(invden.alloc(n * 8)); SHP_TRY(gmax.alloc(8));
         SHP_TRY(launch_guide_stats(dg.p, guide_dtype, H, W, p->guided_radius, p->guided_eps, mean.as<double>(),
                                    invden.as<double>(), gmax.p, nullptr));

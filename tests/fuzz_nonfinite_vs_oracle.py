@@ -14,6 +14,7 @@ import numpy as np  # noqa: E402
 
 import filters  # noqa: E402
 import guided_filter as gf  # noqa: E402
+import stereo  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 
@@ -37,9 +38,24 @@ def run_cases(n_cases: int, seed: int) -> int:
         img = (rng.random((h, w)) * 100).astype(np.float32)
         for _ in range(int(rng.integers(1, 4))):
             img[rng.integers(0, h), rng.integers(0, w)] = rng.choice([np.nan, np.inf, -np.inf])
-        op = str(rng.choice(["integral", "box", "guided", "gaussian", "bilateral", "median"]))
+        op = str(rng.choice(["integral", "box", "guided", "gaussian", "bilateral", "median", "agg"]))
         try:
-            if op == "integral":
+            if op == "agg":
+                # aggregate_and_wta on a volume with non-finite costs: the guided filter spreads them per layer
+                nd = int(rng.integers(1, 7))
+                dsi = (np.round(rng.random((h, w, nd)) * 400) / 4).astype(np.float32)
+                for _ in range(int(rng.integers(1, 3))):
+                    dsi[rng.integers(0, h), rng.integers(0, w), rng.integers(0, nd)] = rng.choice([np.nan, np.inf, -np.inf])
+                guide = rng.random((h, w)).astype(np.float32)
+                filt = str(rng.choice(["guided", "gaussian", "bilateral"]))
+                kind = {"guided": orc.FILTER_GUIDED, "gaussian": orc.FILTER_GAUSSIAN, "bilateral": orc.FILTER_BILATERAL}[filt]
+                dref, cref = orc.aggregate_and_wta(dsi, guide, kind, 3 if filt == "guided" else 0, 0.0154 if filt == "guided" else 1.0)[:2]
+                d, c = stereo.aggregate_and_wta(dsi, guide, 3, 0.0154, filter_type=filt)
+                ok, why = same(np.where(d == dref, c, cref), cref, 1e-5)
+                if ok and np.mean(d == dref) < 0.98:
+                    ok, why = False, f"disparity agreement {np.mean(d == dref):.3f}"
+                why = f"{filt} {why}"
+            elif op == "integral":
                 ok, why = same(gf.integral_image(img), orc.integral_image(img))
             elif op == "box":
                 r = int(rng.integers(0, 5)); ok, why = same(gf.box_filter_mean(img, r), orc.box_filter_mean(img, r))
