@@ -95,13 +95,22 @@ __global__ __launch_bounds__(256) void census_pack_kernel(const T *__restrict__ 
     const T *__restrict__ img = blockIdx.z ? img1 : img0;
     WordT *__restrict__ words = blockIdx.z ? words1 : words0;
     const int x0 = blockIdx.x * CP_TW, y0 = blockIdx.y * CP_TH;
-    for (int i = threadIdx.x; i < LW * LH; i += 256) {
+    // every load of the tile is issued before the first one is used (addresses clamped into the image, so
+    // no branch separates the loads)
+    constexpr int NLD = (LW * LH + 255) / 256;
+    T v[NLD];
+    bool in[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int i = min((int)threadIdx.x + u * 256, LW * LH - 1);
         const int ly = i / LW, lx = i - ly * LW;
         const int gy = y0 - R + ly, gx = x0 - R + lx;
-        T v = census_lowest<T>();
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img[(size_t)gy * W + gx];
-        tile[i] = v;
+        in[u] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        v[u] = img[(size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
     }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+        if ((int)threadIdx.x + u * 256 < LW * LH) tile[threadIdx.x + u * 256] = in[u] ? v[u] : census_lowest<T>();
     __syncthreads();
     constexpr int dys[8] = {1, -1, 0, 0, 1, 1, -1, -1};
     constexpr int dxs[8] = {0, 0, 1, -1, 1, -1, 1, -1};

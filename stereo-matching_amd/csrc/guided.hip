@@ -39,12 +39,22 @@ __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__
     double *hs1 = tile + LW * LH;          // [LH][GS_TW] horizontal sums of G
     double *hs2 = hs1 + LH * GS_TW;        // [LH][GS_TW] horizontal sums of G*G
     const int x0 = blockIdx.x * GS_TW, y0 = blockIdx.y * GS_TH;
-    for (int i = threadIdx.x; i < LW * LH; i += blockDim.x) {
-        int ly = i / LW, lx = i - ly * LW;
-        int gy = y0 - R + ly, gx = x0 - R + lx;
-        double v = 0.0;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = (double)guide[(size_t)gy * W + gx];
-        tile[i] = v;
+    // four loads per thread are in flight at a time (addresses clamped into the image, so no branch
+    // separates them); cells outside the image are stored as 0
+    for (int i0 = threadIdx.x; i0 < LW * LH; i0 += 4 * 256) {
+        GT v[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * 256, LW * LH - 1);
+            const int ly = i / LW, lx = i - ly * LW;
+            const int gy = y0 - R + ly, gx = x0 - R + lx;
+            in[u] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            v[u] = guide[(size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * 256 < LW * LH) tile[i0 + u * 256] = in[u] ? (double)v[u] : 0.0;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < LH * GS_TW; i += blockDim.x) {

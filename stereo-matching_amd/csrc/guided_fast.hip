@@ -254,25 +254,54 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     const float inv_scale_f = ldexpf(1.f, -sh);
     const double inv_scale_d = (double)inv_scale_f;
 
-    for (int idx = threadIdx.x; idx < NI * 64; idx += NW * 64) {
-        int i = idx >> 6, l = idx & 63;
-        int gy = ty0 - HALO + i, gx = tx0 - HALO + l;
-        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        float g = in ? a.guide[(size_t)gy * W + gx] : 0.f;
-        int kk = __float2int_rn(g * scale_f);
-        t.k[idx] = (short)kk;
-        t.glo[idx] = fmaf(-(float)kk, inv_scale_f, g);
-        t.L[idx] = in ? lw[(size_t)gy * W + gx] : WordT(0);
-        int o = i - HALO;
-        if (o >= 0 && o < TH) t.gout[o * 64 + l] = g;
-    }
-    for (int idx = threadIdx.x; idx < NJ * 64; idx += NW * 64) {
-        int j = idx >> 6, l = idx & 63;
-        int gy = ty0 - RG + j, gx = tx0 - HALO + l;
-        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        t.mG[idx] = in ? a.mean[(size_t)gy * W + gx] : 0.0;
-        const int cyy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1, cxx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
-        t.inv[idx] = in ? (float)(a.invden[(size_t)gy * W + gx] / (double)(cyy * cxx)) : 0.f;
+    // Staging: every global load of the tile is issued before the first result is used (one memory round
+    // trip; the workgroup owns the compute unit's LDS, so nothing else would hide the latency).  Addresses
+    // are clamped into the image, cells outside it are zeroed when they are stored.
+    {
+        const int l = threadIdx.x & 63, i_first = threadIdx.x >> 6;
+        constexpr int N1 = (NI + NW - 1) / NW, N2 = (NJ + NW - 1) / NW;
+        const int gx = tx0 - HALO + l;
+        const bool gx_in = gx >= 0 && gx < W;
+        const int gxc = min(max(gx, 0), W - 1);
+        float g_in[N1];
+        WordT l_in[N1];
+        double m_in[N2], d_in[N2];
+#pragma unroll
+        for (int u = 0; u < N1; ++u) {
+            const int gyc = min(max(ty0 - HALO + i_first + u * NW, 0), H - 1);
+            g_in[u] = a.guide[(size_t)gyc * W + gxc];
+            l_in[u] = lw[(size_t)gyc * W + gxc];
+        }
+#pragma unroll
+        for (int u = 0; u < N2; ++u) {
+            const int gyc = min(max(ty0 - RG + i_first + u * NW, 0), H - 1);
+            m_in[u] = a.mean[(size_t)gyc * W + gxc];
+            d_in[u] = a.invden[(size_t)gyc * W + gxc];
+        }
+#pragma unroll
+        for (int u = 0; u < N1; ++u) {
+            const int i = i_first + u * NW;
+            if (i >= NI) break;
+            const int gy = ty0 - HALO + i, idx = i * 64 + l;
+            const bool in = gx_in && gy >= 0 && gy < H;
+            const float g = in ? g_in[u] : 0.f;
+            const int kk = __float2int_rn(g * scale_f);
+            t.k[idx] = (short)kk;
+            t.glo[idx] = fmaf(-(float)kk, inv_scale_f, g);
+            t.L[idx] = in ? l_in[u] : WordT(0);
+            const int o = i - HALO;
+            if (o >= 0 && o < TH) t.gout[o * 64 + l] = g;
+        }
+#pragma unroll
+        for (int u = 0; u < N2; ++u) {
+            const int j = i_first + u * NW;
+            if (j >= NJ) break;
+            const int gy = ty0 - RG + j, idx = j * 64 + l;
+            const bool in = gx_in && gy >= 0 && gy < H;
+            t.mG[idx] = in ? m_in[u] : 0.0;
+            const int cyy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1, cxx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
+            t.inv[idx] = in ? (float)(d_in[u] / (double)(cyy * cxx)) : 0.f;
+        }
     }
     for (int idx = threadIdx.x; idx < TH * 64; idx += NW * 64) t.key[idx] = SHP_KEY_INIT;
     if (threadIdx.x < 16) t.gout[TH * 64 + threadIdx.x] = 0.f;

@@ -382,29 +382,62 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
     if (threadIdx.x == 0) { t.next_d[0] = 0; t.next_d[1] = 0x7fffffff; t.next_d[2] = 0; }
     __syncthreads();
     bool finite_in = __float_as_uint(a.gmax[1]) == 0u;
-    for (int idx = threadIdx.x; idx < NI * TC; idx += NW * 64) {
-        int i = idx / TC, c = idx % TC;
-        int gy = ty0 - HALO + i, gx = tx0 - HALO + c;
-        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        float g = in ? a.guide[(size_t)gy * W + gx] : 0.f;
-        finite_in = finite_in && fabsf(g) <= 3.0e38f;
-        int kk = __float2int_rn(g * scale_f);
-        t.k[idx] = (short)kk;
-        t.glo[idx] = fmaf(-(float)kk, inv_scale_f, g);
-        t.L[idx] = in ? lw[(size_t)gy * W + gx] : WordT(0);
-        int o = i - HALO;
-        if (o >= 0 && o < TH) t.gout[o * TC + c] = g;
-    }
-    for (int idx = threadIdx.x; idx < NJ * TC; idx += NW * 64) {
-        int j = idx / TC, c = idx % TC;
-        int gy = ty0 - RG + j, gx = tx0 - HALO + c;
-        bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const double mg = in ? a.mean[(size_t)gy * W + gx] : 0.0;
-        t.mG[j * TC + deint(c)] = mg;
-        const int cyy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1, cxx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
-        const float iv = in ? (float)(a.invden[(size_t)gy * W + gx] / (double)(cyy * cxx)) : 0.f;
-        t.inv[j * TC + deint(c)] = iv;
-        finite_in = finite_in && fabs(mg) <= 1.0e300 && fabsf(iv) <= 3.0e38f;
+    // Staging.  A workgroup owns its compute unit's whole LDS, so nothing else runs while the tile is
+    // fetched: every global load of the tile is issued before the first result is used (one memory
+    // round trip instead of one per loop iteration).  Addresses are clamped into the image so that the
+    // loads need no branch; cells outside the image are zeroed when they are stored.
+    {
+        constexpr int NT = NW * 64;
+        static_assert(NT % TC == 0, "a thread keeps its tile column in every staging step");
+        constexpr int RSTEP = NT / TC;                      // tile rows between two steps of a thread
+        constexpr int N1 = (NI + RSTEP - 1) / RSTEP, N2 = (NJ + RSTEP - 1) / RSTEP;
+        const int c = threadIdx.x % TC, i_first = threadIdx.x / TC;
+        const int gx = tx0 - HALO + c;
+        const bool x_in = gx >= 0 && gx < W;
+        const int gxc = min(max(gx, 0), W - 1);
+        float g_in[N1];
+        WordT l_in[N1];
+        double m_in[N2], d_in[N2];
+#pragma unroll
+        for (int u = 0; u < N1; ++u) {
+            const int gyc = min(max(ty0 - HALO + i_first + u * RSTEP, 0), H - 1);
+            g_in[u] = a.guide[(size_t)gyc * W + gxc];
+            l_in[u] = lw[(size_t)gyc * W + gxc];
+        }
+#pragma unroll
+        for (int u = 0; u < N2; ++u) {
+            const int gyc = min(max(ty0 - RG + i_first + u * RSTEP, 0), H - 1);
+            m_in[u] = a.mean[(size_t)gyc * W + gxc];
+            d_in[u] = a.invden[(size_t)gyc * W + gxc];
+        }
+#pragma unroll
+        for (int u = 0; u < N1; ++u) {
+            const int i = i_first + u * RSTEP;
+            if (i >= NI) break;
+            const int gy = ty0 - HALO + i, idx = i * TC + c;
+            const bool in = x_in && gy >= 0 && gy < H;
+            const float g = in ? g_in[u] : 0.f;
+            finite_in = finite_in && fabsf(g) <= 3.0e38f;
+            const int kk = __float2int_rn(g * scale_f);
+            t.k[idx] = (short)kk;
+            t.glo[idx] = fmaf(-(float)kk, inv_scale_f, g);
+            t.L[idx] = in ? l_in[u] : WordT(0);
+            const int o = i - HALO;
+            if (o >= 0 && o < TH) t.gout[o * TC + c] = g;
+        }
+#pragma unroll
+        for (int u = 0; u < N2; ++u) {
+            const int j = i_first + u * RSTEP;
+            if (j >= NJ) break;
+            const int gy = ty0 - RG + j;
+            const bool in = x_in && gy >= 0 && gy < H;
+            const double mg = in ? m_in[u] : 0.0;
+            t.mG[j * TC + deint(c)] = mg;
+            const int cyy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1, cxx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
+            const float iv = in ? (float)(d_in[u] / (double)(cyy * cxx)) : 0.f;
+            t.inv[j * TC + deint(c)] = iv;
+            finite_in = finite_in && fabs(mg) <= 1.0e300 && fabsf(iv) <= 3.0e38f;
+        }
     }
     if (!finite_in) t.next_d[2] = 1;  // (after the barrier below it reads 0 unless some thread saw a non-finite input)
     for (int idx = threadIdx.x; idx < TH * TC; idx += NW * 64) t.key[idx] = SHP_KEY_INIT;
