@@ -34,7 +34,7 @@ WORKLOADS = {
                    "Motorcycle-perfect shaped synthetic pair 2964x2000, dmax=270, wct_radius=4, guided r=3 eps=0.0154"),
     "4k": (2160, 3840, 512, 4, 3840,
            "synthetic 3840x2160 pair, dmax=512, wct_radius=4, guided r=3 eps=0.0154"),
-    # BASELINE config 5: census radius 8 with the other aggregation filters (chosen with --filter)
+    # the 8K benchmark configuration: census radius 8 with the other aggregation filters (chosen with --filter)
     "8k": (4320, 7680, 256, 8, 7680, "synthetic 7680x4320 pair, dmax=256, wct_radius=8"),
 }
 FILTERS = {"guided": "FILTER_GUIDED", "median": "FILTER_MEDIAN_U8Q", "gaussian": "FILTER_GAUSSIAN",

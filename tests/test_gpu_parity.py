@@ -3,7 +3,7 @@ libstereo_hip.so) against the golden vectors captured from the reference and aga
 oracle on seeded inputs.
 
 Bars: the WCT cost volume, disparities of integer-valued filters and every index result are
-bit-exact; float filter outputs agree within 1e-5 relative (BASELINE.json north_star), and a
+bit-exact; float filter outputs agree within 1e-5 relative (the stated parity bar of this project), and a
 disparity may differ from the reference only where the reference's own filtered costs of the two
 candidates are within that tolerance ("gap-aware").
 """
@@ -359,7 +359,7 @@ def test_filters_through_wta_golden(oracle):
 
 
 def test_radius8_filters_fused_golden(oracle):
-    """BASELINE config 5 in miniature: census radius 8 with median / gaussian / bilateral."""
+    """The 8K benchmark configuration in miniature: census radius 8 with median / gaussian / bilateral."""
     import stereo
     g = load_golden("radius8_40x72x12")
     left, right, dsi = g["left"], g["right"], g["dsi"]
@@ -459,7 +459,7 @@ def test_compute_disparity_other_filters_vs_oracle(oracle, filt, kw, okind, orad
         assert_wta_matches(d, c, dref, cref, layers, min_agree=min_agree)
 
 
-# ------------------------------------------------------------------ BASELINE-size checks
+# ------------------------------------------------------------------ full-size (Motorcycle-shaped) checks
 
 @pytest.fixture(scope="module")
 def motorcycle_pair():

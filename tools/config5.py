@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE config 5 (7680x4320, dmax 256, census radius 8; median / gaussian / bilateral) through the
+"""The 8K benchmark configuration (7680x4320, dmax 256, census radius 8; median / gaussian / bilateral) through the
 public compute_disparity call: wall time of the whole call, host copies included."""
 import os
 import sys
