@@ -81,6 +81,21 @@ template <> __device__ __forceinline__ float census_lowest<float>() { return -__
 template <> __device__ __forceinline__ double census_lowest<double>() { return -__builtin_inf(); }
 template <> __device__ __forceinline__ uint8_t census_lowest<uint8_t>() { return 0; }
 
+// word * 2 + (n > c): the next census bit enters at the low end.
+template <typename T, typename WordT>
+__device__ __forceinline__ WordT shift_in_greater(WordT word, T n, T c) {
+    return (WordT)((word << 1) | (WordT)(n > c ? 1 : 0));
+}
+// float32 pixels, 32-bit words: compare into the carry, then word + word + carry -- two instructions per
+// neighbour where the generic form compiles to three (compare, select 0 / 1, shift-or); the kernel is bound by
+// its vector instructions.
+template <>
+__device__ __forceinline__ uint32_t shift_in_greater<float, uint32_t>(uint32_t word, float n, float c) {
+    uint32_t out;
+    asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %3, vcc" : "=v"(out) : "v"(n), "v"(c), "v"(word) : "vcc");
+    return out;
+}
+
 // One packed census word per pixel.  blockIdx.z selects the image, so the left and the right image
 // of a pair are packed by one launch.  The tile and its halo are staged in LDS with out-of-image
 // cells set to the lowest value; bits are shifted in from the most significant one down (direction 7
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(256) void census_pack_kernel(const T *__restrict__ 
 #pragma unroll
         for (int k = 7; k >= 0; --k) {
 #pragma unroll
-            for (int r = 1; r <= R; ++r) word = (word << 1) | (WordT)(c0[dys[k] * r * LW + dxs[k] * r] > c ? 1 : 0);
+            for (int r = 1; r <= R; ++r) word = shift_in_greater(word, c0[dys[k] * r * LW + dxs[k] * r], c);
             if (FB > R) word <<= (k > 0 ? FB - R : 0);
         }
         // ring r of direction k sits at bit FB * k + (FB - r)
