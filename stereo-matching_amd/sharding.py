@@ -154,7 +154,8 @@ class OverlappedExchange:
             for i, b in enumerate(self.bands):
                 wait_band_fn(i, epoch)
                 if not self.use_dist:
-                    unpack_fn(b.send, b.n, b.y0 * self.width)
+                    if rank == 0:   # (a rank without a process group keeps its keys in self.keys)
+                        unpack_fn(b.send, b.n, b.y0 * self.width)
                     continue
                 # one band at a time, start to finish: this stream must not block on the flag of band
                 # i+1 (which may be a long way off) with work of band i still undone
@@ -219,6 +220,10 @@ class ShardedFrameSearch:
             self._left.data_ptr(), self._right.data_ptr(), self.H, self.W, self.D, self.params, self.d_begin, self.d_end,
             self.workspace.data_ptr(), self.ws_bytes, keys.data_ptr(), self.n_bands, self.progress.data_ptr(), epoch,
             self._stream()))
+
+    def disparities_searched(self) -> int:
+        """Number of disparities this rank searches per frame."""
+        return self.d_end - self.d_begin
 
     def _wait(self, band, epoch) -> None:
         self._native.check(self.lib.stereo_wait_progress_dev(self.progress.data_ptr(), band, epoch, self._stream()))

@@ -198,3 +198,42 @@ def test_progress_reporting_random_shapes():
         tag = f"case {case}: {w}x{h} dmax {dmax} d[{d0},{d1}) {filt} bands {bands}->{n_bands.value}"
         assert list(words[16:16 + n_bands.value]) == [7] * n_bands.value and not words[32:48].any(), tag
         assert torch.equal(keys, plain), tag
+
+
+@pytest.mark.parametrize("filt,world", [("guided", 3), ("guided", 8), ("median", 3)])
+def test_sharded_frame_search_ranks_merge_to_the_plain_search(filt, world):
+    """ShardedFrameSearch as every rank of a `world`-rank job in turn (no process group: each rank's keys stay in
+    its exchange buffer): the key-wise minimum over the ranks' contiguous disparity ranges is the whole-range search."""
+    import torch
+
+    import _native
+    import sharding
+    from synth import synth_pair_gray
+
+    lib = _native.lib()
+    dev = torch.device("cuda", 0)
+    h, w, dmax = 140, 330, 37
+    left_np, right_np, _ = synth_pair_gray(h, w, dmax, seed=77)
+    left, right = torch.from_numpy(left_np).to(dev).view(-1), torch.from_numpy(right_np).to(dev).view(-1)
+    params = _params(_native, filt)
+    main = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nbytes = ctypes.c_size_t(0)
+    _native.check(lib.stereo_fused_workspace_bytes(h, w, params, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    plain = torch.empty(h * w, dtype=torch.int64, device=dev)
+    _native.check(lib.stereo_compute_disparity_dev(left.data_ptr(), right.data_ptr(), h, w, dmax, params, 0, dmax,
+                                                   ws.data_ptr(), nbytes.value, plain.data_ptr(), main))
+    slices = torch.empty(world * h * w, dtype=torch.int64, device=dev)
+    searched = 0
+    for rank in range(world):
+        search = sharding.ShardedFrameSearch(h, w, dmax, params, world, rank, dev, n_bands=3, use_dist=False)
+        searched += search.disparities_searched()
+        disp, cost = search.run(left, right)
+        assert (disp is None) == (rank != 0)
+        torch.cuda.synchronize()
+        assert search.band_waits_timed_out() == 0
+        slices[rank * h * w:(rank + 1) * h * w] = search.exchange.keys[:h * w]
+    assert searched == dmax
+    _native.check(lib.stereo_merge_key_slices_dev(slices.data_ptr(), h * w, world, main))
+    torch.cuda.synchronize()
+    assert torch.equal(slices[:h * w], plain)
