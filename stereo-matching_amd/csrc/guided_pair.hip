@@ -367,7 +367,29 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
     if (a.gate_min > 0.f && !eps_gate_takes_fast(a.gate_eps, a.gate_min, *a.gmax)) return;
     const int lane = threadIdx.x & 63;
     const int H = a.H, W = a.W;
-    const int tx0 = blockIdx.x * TWV, ty0 = blockIdx.y * TH;
+    // Tile order.  Workgroups start in the order of blockIdx.x.  Rows are grouped in bands (the bands of the
+    // progress report, or one band for the whole frame); inside a band the tiles run column by column from the
+    // right edge to the left.  Tiles near the left edge skip the disparities beyond their columns and are the
+    // cheapest, so they fill the end of the launch, where a compute unit that gets a long tile late would leave
+    // the others idle; for the same reason the slowest tiles of the last band start it.
+    const int nx = (a.W + TWV - 1) / TWV, ny = (a.H + TH - 1) / TH;
+    const int band_rows_max = a.band_tile_rows > 0 ? a.band_tile_rows : ny;
+    const int tile_band = (int)blockIdx.x / (band_rows_max * nx);
+    const int tile_band_rows = min(band_rows_max, ny - tile_band * band_rows_max);
+    const int in_band = (int)blockIdx.x - tile_band * band_rows_max * nx;
+    int tile_x = nx - 1 - in_band / tile_band_rows, tile_y = tile_band * band_rows_max + in_band % tile_band_rows;
+    if (tile_band * band_rows_max + tile_band_rows == ny) {
+        // last band: the bottom row of tiles (clipped windows, the slower code variant) goes first
+        if (in_band < nx) {
+            tile_x = nx - 1 - in_band;
+            tile_y = ny - 1;
+        } else {
+            const int j = in_band - nx, rows = tile_band_rows - 1;
+            tile_x = nx - 1 - j / rows;
+            tile_y = tile_band * band_rows_max + j % rows;
+        }
+    }
+    const int tx0 = tile_x * TWV, ty0 = tile_y * TH;
     const WordT *lw = static_cast<const WordT *>(a.lw);
 
     const float gmax = *a.gmax;
@@ -527,11 +549,9 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the stores above have been acknowledged
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int band = (int)blockIdx.y / a.band_tile_rows;
-            const int band_rows = min(a.band_tile_rows, (int)gridDim.y - band * a.band_tile_rows);
-            const uint32_t total = (uint32_t)band_rows * gridDim.x * gridDim.z;
-            if (atomicAdd(&a.progress[band], 1u) + 1u == total) {
-                __hip_atomic_store(&a.progress[PROGRESS_MAX_BANDS + band], a.epoch, __ATOMIC_RELEASE,
+            const uint32_t total = (uint32_t)tile_band_rows * nx * gridDim.z;
+            if (atomicAdd(&a.progress[tile_band], 1u) + 1u == total) {
+                __hip_atomic_store(&a.progress[PROGRESS_MAX_BANDS + tile_band], a.epoch, __ATOMIC_RELEASE,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -570,7 +590,7 @@ static int launch_pair_q(const FastArgs &a, hipStream_t s) {
     auto kern = fused_guided_pair_kernel<RG, WORD64, TH, FP_NW, QOUT>;
     SHP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
-    dim3 grid(ceil_div(a.W, 128 - 4 * RG), ceil_div(a.H, TH), a.n_slices);
+    dim3 grid(ceil_div(a.W, 128 - 4 * RG) * ceil_div(a.H, TH), 1, a.n_slices);
     hipLaunchKernelGGL(kern, grid, dim3(FP_NW * 64), smem, s, a);
     SHP_LAUNCH_CHECK();
     return STEREO_OK;
