@@ -22,6 +22,10 @@ struct FastArgs {
     float unit;             // value of one cost unit
     uint32_t large_units;   // `large` in cost units
     int atomic_out;
+    // Tail split (two-column kernel): workgroups from index split_first on are slices of tiles -- tile
+    // split_first + (b - split_first) / split_slices, slice (b - split_first) % split_slices of split_slices --
+    // so that the last, partly filled round of workgroups is made of short ones.  split_slices <= 1: none.
+    int split_first, split_slices;
     // Row-band progress for callers that ship finished rows while the rest is searched:
     // words[b] counts the finished workgroups of band b, words[16 + b] receives `epoch` when the
     // band's rows are final in `keys`.  nullptr = no reporting.

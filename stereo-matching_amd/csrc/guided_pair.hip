@@ -13,8 +13,13 @@
 //    2r + 2 instructions for two columns instead of 4r.
 // Workgroups are 8 wavefronts (the per-lane state is twice as large), each marching down the
 // tile rows for one disparity at a time.
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "fast_common.hpp"
 
@@ -338,6 +343,34 @@ __device__ __forceinline__ void pair_disparity_pass(
     for (int base = 2 * WIN; base < NI; base += WIN) row_group(base, std::true_type{});
 }
 
+// Tile order.  Workgroups start in the order of their index.  Rows are grouped in bands (the bands of the
+// progress report, or one band for the whole frame); inside a band the tiles run column by column from the
+// right edge to the left.  Tiles near the left edge skip the disparities beyond their columns and are the
+// cheapest, so they fill the end of the launch, where a compute unit that gets a long tile late would leave
+// the others idle; for the same reason the bottom row of tiles (clipped windows, the slower code variant)
+// starts the last band.
+struct TilePos { int x, y, band, band_rows; };
+__host__ __device__ inline TilePos pair_tile_of_index(int index, int nx, int ny, int band_rows_max) {
+    TilePos p;
+    p.band = index / (band_rows_max * nx);
+    const int first_row = p.band * band_rows_max;
+    p.band_rows = band_rows_max < ny - first_row ? band_rows_max : ny - first_row;
+    const int in_band = index - first_row * nx;
+    p.x = nx - 1 - in_band / p.band_rows;
+    p.y = first_row + in_band % p.band_rows;
+    if (first_row + p.band_rows == ny) {
+        if (in_band < nx) {
+            p.x = nx - 1 - in_band;
+            p.y = ny - 1;
+        } else {
+            const int j = in_band - nx, rows = p.band_rows - 1;
+            p.x = nx - 1 - j / rows;
+            p.y = first_row + j % rows;
+        }
+    }
+    return p;
+}
+
 template <int RG, bool WORD64, int TH, int NW, bool QOUT>
 __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) {
     constexpr int WIN = 2 * RG + 1;
@@ -367,28 +400,19 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
     if (a.gate_min > 0.f && !eps_gate_takes_fast(a.gate_eps, a.gate_min, *a.gmax)) return;
     const int lane = threadIdx.x & 63;
     const int H = a.H, W = a.W;
-    // Tile order.  Workgroups start in the order of blockIdx.x.  Rows are grouped in bands (the bands of the
-    // progress report, or one band for the whole frame); inside a band the tiles run column by column from the
-    // right edge to the left.  Tiles near the left edge skip the disparities beyond their columns and are the
-    // cheapest, so they fill the end of the launch, where a compute unit that gets a long tile late would leave
-    // the others idle; for the same reason the slowest tiles of the last band start it.
     const int nx = (a.W + TWV - 1) / TWV, ny = (a.H + TH - 1) / TH;
-    const int band_rows_max = a.band_tile_rows > 0 ? a.band_tile_rows : ny;
-    const int tile_band = (int)blockIdx.x / (band_rows_max * nx);
-    const int tile_band_rows = min(band_rows_max, ny - tile_band * band_rows_max);
-    const int in_band = (int)blockIdx.x - tile_band * band_rows_max * nx;
-    int tile_x = nx - 1 - in_band / tile_band_rows, tile_y = tile_band * band_rows_max + in_band % tile_band_rows;
-    if (tile_band * band_rows_max + tile_band_rows == ny) {
-        // last band: the bottom row of tiles (clipped windows, the slower code variant) goes first
-        if (in_band < nx) {
-            tile_x = nx - 1 - in_band;
-            tile_y = ny - 1;
-        } else {
-            const int j = in_band - nx, rows = tile_band_rows - 1;
-            tile_x = nx - 1 - j / rows;
-            tile_y = tile_band * band_rows_max + j % rows;
-        }
+    // whole tiles first, then the slices of the split tiles
+    int tile_index = (int)blockIdx.x, slice = (int)blockIdx.z, n_slices = a.n_slices;
+    bool atomic_out = a.atomic_out != 0;
+    if (a.split_slices > 1 && tile_index >= a.split_first) {
+        const int r = tile_index - a.split_first;
+        tile_index = a.split_first + r / a.split_slices;
+        slice = r % a.split_slices;
+        n_slices = a.split_slices;
+        atomic_out = true;
     }
+    const TilePos tp = pair_tile_of_index(tile_index, nx, ny, a.band_tile_rows > 0 ? a.band_tile_rows : ny);
+    const int tile_x = tp.x, tile_y = tp.y, tile_band = tp.band, tile_band_rows = tp.band_rows;
     const int tx0 = tile_x * TWV, ty0 = tile_y * TH;
     const WordT *lw = static_cast<const WordT *>(a.lw);
 
@@ -506,7 +530,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         // lane-dependent branch surrounds the hand-out: a `lane == 0` guard here lets the optimiser
         // specialise the loop for the other lanes, for which the guarded value is a constant.
         const int dn = __builtin_amdgcn_readfirstlane(atomicAdd(t.next_d, 1)) >> 6;
-        const int d = a.d_begin + dn * a.n_slices + (int)blockIdx.z;
+        const int d = a.d_begin + dn * n_slices + slice;
         if (d >= a.d_end || dn >= n_disp) break;
         // every column of the tile lies left of the first valid match: all costs are `large`
         if (!QOUT && tx0 - HALO + (TC - 1) - d < R) {
@@ -532,7 +556,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
                 const uint64_t kl = make_key(large_f, (uint32_t)skipped_d);
                 key = kl < key ? kl : key;
             }
-            if (a.atomic_out) atomicMin(reinterpret_cast<unsigned long long *>(&a.keys[(size_t)gy * W + gx]),
+            if (atomic_out) atomicMin(reinterpret_cast<unsigned long long *>(&a.keys[(size_t)gy * W + gx]),
                                         (unsigned long long)key);
             // device-scope store: written through this XCD's L2, so that a reader on another XCD sees it
             // without this workgroup flushing the whole L2 (which a device-scope fence would do)
@@ -549,7 +573,10 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the stores above have been acknowledged
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t total = (uint32_t)tile_band_rows * nx * gridDim.z;
+            // workgroups of the band: its tiles, the split ones (all in the last band) counted once per slice
+            uint32_t total = (uint32_t)tile_band_rows * nx * gridDim.z;
+            if (a.split_slices > 1 && tile_band * a.band_tile_rows + tile_band_rows == ny)
+                total += (uint32_t)(nx * ny - a.split_first) * (uint32_t)(a.split_slices - 1);
             if (atomicAdd(&a.progress[tile_band], 1u) + 1u == total) {
                 __hip_atomic_store(&a.progress[PROGRESS_MAX_BANDS + tile_band], a.epoch, __ATOMIC_RELEASE,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
@@ -590,7 +617,8 @@ static int launch_pair_q(const FastArgs &a, hipStream_t s) {
     auto kern = fused_guided_pair_kernel<RG, WORD64, TH, FP_NW, QOUT>;
     SHP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
-    dim3 grid(ceil_div(a.W, 128 - 4 * RG) * ceil_div(a.H, TH), 1, a.n_slices);
+    const int tiles = ceil_div(a.W, 128 - 4 * RG) * ceil_div(a.H, TH);
+    dim3 grid(a.split_slices > 1 ? a.split_first + (tiles - a.split_first) * a.split_slices : tiles, 1, a.n_slices);
     hipLaunchKernelGGL(kern, grid, dim3(FP_NW * 64), smem, s, a);
     SHP_LAUNCH_CHECK();
     return STEREO_OK;
@@ -626,6 +654,79 @@ int fused_pair_slices(int H, int W, int guided_radius, bool word64, int n_disp) 
     return s;
 }
 
+// ---- tail split -----------------------------------------------------------------------------------------
+// A compute unit holds one workgroup (the tile image fills its LDS), so a launch runs in rounds of as many
+// workgroups as there are units, and the last round is usually partly empty: 1742 tiles on 256 units are 6.8
+// rounds that take the time of 7.  The planner below replays the launch on a model of the chip (greedy
+// assignment of workgroups, in index order, to the unit that frees first; a workgroup costs one unit of
+// time per round of NW passes plus a fixed share) for a few ways of cutting the last tiles into
+// disparity slices, and keeps the best one if it saves at least 1.5 %.  Split tiles merge their slices with
+// atomicMin on the key array, which the launcher then fills with the initial key first.
+struct SplitPlan { int first, slices; };
+
+static SplitPlan plan_tail_split(int W, int H, int th, int rg, int census_radius, int d_begin, int d_end,
+                                 int band_rows_max, int n_units) {
+    const int twv = 128 - 4 * rg, halo = 2 * rg;
+    const int nx = ceil_div(W, twv), ny = ceil_div(H, th), T = nx * ny;
+    SplitPlan none = {T, 1};
+    if (n_units <= 0 || T < n_units) return none;
+    // fixed share of a workgroup (staging, key write-out, the ragged last round of its wavefronts) in passes, and the
+    // slower code variant of border tiles: fitted to measured launches (Motorcycle-sized frame, 13 ways of splitting)
+    constexpr double STAGING = 1.0, BORDER = 1.12;
+    auto cost = [&](int index, int slice, int n_slices) {
+        const TilePos tp = pair_tile_of_index(index, nx, ny, band_rows_max);
+        const int tx0 = tp.x * twv, ty0 = tp.y * th;
+        const int lim = std::min(d_end, tx0 - halo + 127 - census_radius + 1);   // passes at d >= lim are skipped
+        const int span = lim - d_begin - slice;
+        const int passes = span > 0 ? ceil_div(span, n_slices) : 0;
+        const bool interior = (ty0 - halo >= census_radius) && (ty0 + th + halo <= H - census_radius);
+        return ceil_div(passes, FP_NW) * (interior ? 1.0 : BORDER) + STAGING;
+    };
+    // split tiles must all lie in the last band (the progress count of the other bands stays plain)
+    const int last_band_first = ((ny - 1) / band_rows_max) * band_rows_max * nx;
+    const int earliest = std::max(std::max(0, T - 2 * n_units), last_band_first);
+    std::vector<double> units((size_t)n_units, 0.0);
+    auto push_job = [](std::vector<double> &h, double c) {   // min-heap on the time a unit frees
+        std::pop_heap(h.begin(), h.end(), std::greater<double>());
+        h.back() += c;
+        std::push_heap(h.begin(), h.end(), std::greater<double>());
+    };
+    std::make_heap(units.begin(), units.end(), std::greater<double>());
+    for (int i = 0; i < earliest; ++i) push_job(units, cost(i, 0, 1));
+    auto finish = [&](int first, int slices) {
+        std::vector<double> h = units;
+        for (int i = earliest; i < first; ++i) push_job(h, cost(i, 0, 1));
+        for (int i = first; i < T; ++i)
+            for (int z = 0; z < slices; ++z) push_job(h, cost(i, z, slices));
+        return *std::max_element(h.begin(), h.end());
+    };
+    const double plain = finish(T, 1);
+    SplitPlan best = none;
+    double best_t = plain * (1.0 - 0.015);
+    // candidates: whole multiples of a quarter of the units (a split that starts on a round boundary is the best one
+    // when the whole tiles before it take equally long)
+    const int step = std::max(1, n_units / 4);
+    for (int first = (T - 1) / step * step; first >= earliest && first > 0; first -= step)
+        for (int slices : {2, 3, 4, 6, 8}) {
+            if ((d_end - d_begin) / slices < FP_NW) continue;   // a slice should fill the wavefronts at least once
+            const double t = finish(first, slices);
+            if (t < best_t) { best_t = t; best = {first, slices}; }
+        }
+    return best;
+}
+
+static int device_compute_units() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = -1;
+        cached[dev] = n;
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
+}
+
 int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
@@ -648,6 +749,28 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
         a.epoch = progress->epoch;
     }
     const bool w64 = cfg.word64 != 0;
+    a.split_first = 0; a.split_slices = 1;
+    const char *no_split = getenv("STEREO_NO_TAIL_SPLIT");
+    if (a.n_slices == 1 && !d_q_out && !(no_split && atoi(no_split))) {
+        // the plan depends on the frame, the disparity range and the bands only: remember the last one
+        struct Key { int W, H, rg, w64, r, d0, d1, band_rows, units; };
+        static std::mutex mu;
+        static Key last_key = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        static SplitPlan last_plan = {0, 1};
+        const int th = pair_tile_height(guided_radius, w64);
+        const int ny = th > 0 ? ceil_div(H, th) : 0;
+        const Key key = {W, H, guided_radius, w64 ? 1 : 0, cfg.radius, d_begin, d_end,
+                         a.band_tile_rows > 0 ? a.band_tile_rows : ny, device_compute_units()};
+        if (th > 0 && guided_radius >= 1 && guided_radius <= 4) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (memcmp(&key, &last_key, sizeof(Key)) != 0) {
+                last_plan = plan_tail_split(W, H, th, guided_radius, cfg.radius, d_begin, d_end, key.band_rows, key.units);
+                last_key = key;
+            }
+            if (last_plan.slices > 1) { a.split_first = last_plan.first; a.split_slices = last_plan.slices; }
+        }
+    }
+    if (a.split_slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
     switch (guided_radius) {
         case 1: return w64 ? launch_pair_t<1, true>(a, s) : launch_pair_t<1, false>(a, s);
         case 2: return w64 ? launch_pair_t<2, true>(a, s) : launch_pair_t<2, false>(a, s);
