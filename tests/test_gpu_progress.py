@@ -237,3 +237,45 @@ def test_sharded_frame_search_ranks_merge_to_the_plain_search(filt, world):
     _native.check(lib.stereo_merge_key_slices_dev(slices.data_ptr(), h * w, world, main))
     torch.cuda.synchronize()
     assert torch.equal(slices[:h * w], plain)
+
+
+@pytest.mark.parametrize("h,w,dmax,bands", [(1210, 1500, 64, 1), (1210, 1500, 21, 3), (2000, 2964, 40, 4), (700, 3000, 300, 2)])
+def test_tail_split_writes_the_same_keys(h, w, dmax, bands, monkeypatch):
+    """Frames with more tiles than compute units: the launch cuts its last tiles into disparity slices that merge
+    through atomicMin.  Keys and band flags must equal those of the same launch with the split switched off."""
+    import torch
+
+    import _native
+    from synth import synth_pair_gray
+
+    lib = _native.lib()
+    dev = torch.device("cuda", 0)
+    left_np, right_np, _ = synth_pair_gray(h, w, dmax, seed=h)
+    left, right = torch.from_numpy(left_np).to(dev), torch.from_numpy(right_np).to(dev)
+    params = _params(_native)
+    nbytes = ctypes.c_size_t(0)
+    _native.check(lib.stereo_fused_workspace_bytes(h, w, params, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    main = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    row_end = (ctypes.c_int32 * 16)()
+    n_bands = ctypes.c_int(0)
+    _native.check(lib.stereo_progress_plan(h, w, params, bands, row_end, ctypes.byref(n_bands)))
+    results = []
+    for no_split in ("1", "0"):
+        monkeypatch.setenv("STEREO_NO_TAIL_SPLIT", no_split)
+        keys = torch.zeros(h * w, dtype=torch.int64, device=dev)
+        progress = torch.zeros(48, dtype=torch.int32, device=dev)
+        _native.check(lib.stereo_compute_disparity_progress_dev(
+            left.data_ptr(), right.data_ptr(), h, w, dmax, params, 0, dmax, ws.data_ptr(), nbytes.value, keys.data_ptr(),
+            n_bands.value, progress.data_ptr(), 3, main))
+        for b in range(n_bands.value):
+            _native.check(lib.stereo_wait_progress_dev(progress.data_ptr(), b, 3, main))
+        plain = torch.zeros(h * w, dtype=torch.int64, device=dev)
+        _native.check(lib.stereo_compute_disparity_dev(left.data_ptr(), right.data_ptr(), h, w, dmax, params, 0, dmax,
+                                                       ws.data_ptr(), nbytes.value, plain.data_ptr(), main))
+        torch.cuda.synchronize()
+        words = progress.cpu().numpy()
+        assert list(words[16:16 + n_bands.value]) == [3] * n_bands.value and not words[32:48].any()
+        assert torch.equal(keys, plain)
+        results.append(keys)
+    assert torch.equal(results[0], results[1])
