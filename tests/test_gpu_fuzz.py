@@ -29,3 +29,12 @@ def test_non_finite_pixels_through_the_operators(oracle, capsys):
 
     failures = fuzz_nonfinite_vs_oracle.run_cases(300, 5)
     assert failures == 0, capsys.readouterr().out
+
+
+def test_random_large_frames_with_and_without_tail_split(capsys):
+    """Frames with more tiles than compute units: the launch that cuts its last tiles into disparity slices
+    writes the same keys and band flags as the one that does not (see tests/fuzz_tail_split.py)."""
+    import fuzz_tail_split
+
+    failures = fuzz_tail_split.run(40, 3)
+    assert failures == 0, capsys.readouterr().out
