@@ -29,10 +29,12 @@ namespace shp {
 
 constexpr int GS_TW = 64, GS_TH = 16;
 
-template <typename GT>
-__global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__ guide, int H, int W, int R,
+// RT: the radius at compile time (window loops unrolled, tile pitch a constant), 0 = use the argument
+template <typename GT, int RT>
+__global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__ guide, int H, int W, int r_arg,
                                                           double eps32, double *__restrict__ mean,
                                                           double *__restrict__ invden, unsigned int *gmax_bits) {
+    const int R = RT > 0 ? RT : r_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double *tile = reinterpret_cast<double *>(smem_raw);  // [LH][LW] guide, 0 outside the image
     const int LW = GS_TW + 2 * R, LH = GS_TH + 2 * R;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__
     for (int i = threadIdx.x; i < LH * GS_TW; i += blockDim.x) {
         int ly = i >> 6, lx = i & 63;
         double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k <= 2 * R; ++k) {
+        _Pragma("unroll") for (int k = 0; k <= 2 * R; ++k) {
             double g = tile[ly * LW + lx + k];
             s1 += g;
             s2 += g * g;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__
         if (fabs(gv) <= 1.7976931348623157e308) amax = fmaxf(amax, fminf(ag, 3.402823466e38f));
         else nonfinite = true;
         double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k <= 2 * R; ++k) {
+        _Pragma("unroll") for (int k = 0; k <= 2 * R; ++k) {
             s1 += hs1[(ly + k) * GS_TW + lx];
             s2 += hs2[(ly + k) * GS_TW + lx];
         }
@@ -123,11 +125,13 @@ int launch_guide_stats(const void *d_guide, int guide_dtype, int H, int W, int r
     dim3 grid(ceil_div(W, GS_TW), ceil_div(H, GS_TH));
     const int LW = GS_TW + 2 * radius, LH = GS_TH + 2 * radius;
     size_t smem = sizeof(double) * ((size_t)LW * LH + 2 * (size_t)LH * GS_TW);
-    if (guide_dtype == STEREO_DT_F32)
-        hipLaunchKernelGGL(guide_stats_kernel<float>, grid, dim3(256), smem, s,
+    if (guide_dtype == STEREO_DT_F32) {
+        auto kern = radius == 3 ? guide_stats_kernel<float, 3> : radius == 2 ? guide_stats_kernel<float, 2>
+                    : radius == 4 ? guide_stats_kernel<float, 4> : guide_stats_kernel<float, 0>;
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s,
                            static_cast<const float *>(d_guide), H, W, radius, eps32, d_mean, d_invden, gmax_bits);
-    else if (guide_dtype == STEREO_DT_F64)
-        hipLaunchKernelGGL(guide_stats_kernel<double>, grid, dim3(256), smem, s,
+    } else if (guide_dtype == STEREO_DT_F64)
+        hipLaunchKernelGGL((guide_stats_kernel<double, 0>), grid, dim3(256), smem, s,
                            static_cast<const double *>(d_guide), H, W, radius, eps32, d_mean, d_invden, gmax_bits);
     else {
         set_error("guide dtype must be float32 or float64");
