@@ -591,6 +591,27 @@ int stereo_unpack_keys_dev(const uint64_t *d_keys, size_t n, int32_t *d_disp, fl
     return launch_unpack_keys(d_keys, n, d_disp, d_cost, static_cast<hipStream_t>(stream));
 }
 
+// Streams of the host entry point that overlaps its result copy with the search: one per device for the
+// kernels, one for waits, unpacking and copies; created at first use (one caller at a time per device).
+struct HostOverlap {
+    hipStream_t compute = nullptr, copy = nullptr;
+};
+static HostOverlap *host_overlap_for_current_device() {
+    static HostOverlap table[64];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    HostOverlap &h = table[dev];
+    if (!h.compute) {
+        hipStream_t a = nullptr, b = nullptr;
+        if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(a); return nullptr; }
+        h.compute = a; h.copy = b;
+    }
+    return &h;
+}
+
 int stereo_compute_disparity_host(const void *left, const void *right, int dtype, int H, int W, int dmax,
                                   const StereoParams *p, int d_begin, int d_end, int32_t *out_disp,
                                   float *out_cost) {
@@ -623,9 +644,45 @@ int stereo_compute_disparity_host(const void *left, const void *right, int dtype
         SHP_TRY(dl.alloc(n * 4)); SHP_TRY(dr.alloc(n * 4)); SHP_TRY(ws.alloc(L.total));
         SHP_HIP(hipMemcpy(dl.p, hl, n * 4, hipMemcpyHostToDevice));
         SHP_HIP(hipMemcpy(dr.p, hr, n * 4, hipMemcpyHostToDevice));
-        SHP_TRY(fused_disparity_dev(dl.as<float>(), dr.as<float>(), H, W, dmax, p, d_begin, d_end, ws.p, L.total,
-                                    keys.as<uint64_t>(), nullptr, nullptr));
-        SHP_TRY(finish_keys_to_host(keys.as<uint64_t>(), n, out_disp, out_cost));
+        // Large guided frames: the kernel reports finished row bands, and a second stream unpacks each band and
+        // copies it to the caller while the kernel works on the bands below (the device-to-host copy of the two
+        // result planes takes as long as the search itself).
+        HostOverlap *ov = (n >= ((size_t)1 << 20) && d_begin < d_end && progress_tile_rows(p, cfg) > 0)
+                              ? host_overlap_for_current_device() : nullptr;
+        if (ov) {
+            int32_t row_end[PROGRESS_MAX_BANDS];
+            int n_bands = 0;
+            SHP_TRY(stereo_progress_plan(H, W, p, 8, row_end, &n_bands));
+            DevBuf words, disp, cost;
+            SHP_TRY(words.alloc(sizeof(uint32_t) * 3 * PROGRESS_MAX_BANDS));
+            SHP_TRY(disp.alloc(n * 4)); SHP_TRY(cost.alloc(n * 4));
+            SHP_HIP(hipMemsetAsync(words.p, 0, sizeof(uint32_t) * 3 * PROGRESS_MAX_BANDS, ov->compute));
+            int rc = stereo_compute_disparity_progress_dev(dl.as<float>(), dr.as<float>(), H, W, dmax, p, d_begin, d_end,
+                                                           ws.p, L.total, keys.as<uint64_t>(), n_bands,
+                                                           words.as<uint32_t>(), 1u, ov->compute);
+            for (int b = 0, y0 = 0; rc == STEREO_OK && b < n_bands; y0 = row_end[b], ++b) {
+                const size_t first = (size_t)y0 * W, count = (size_t)(row_end[b] - y0) * W;
+                rc = launch_progress_wait(words.as<uint32_t>(), b, 1u, ov->copy);
+                if (rc == STEREO_OK)
+                    rc = launch_unpack_keys(keys.as<uint64_t>() + first, count, disp.as<int32_t>() + first,
+                                            cost.as<float>() + first, ov->copy);
+                if (rc == STEREO_OK && (hipMemcpyAsync(out_disp + first, disp.as<int32_t>() + first, count * 4,
+                                                       hipMemcpyDeviceToHost, ov->copy) != hipSuccess ||
+                                        hipMemcpyAsync(out_cost + first, cost.as<float>() + first, count * 4,
+                                                       hipMemcpyDeviceToHost, ov->copy) != hipSuccess)) {
+                    set_error("device-to-host copy of a row band failed");
+                    rc = STEREO_EHIP;
+                }
+            }
+            // both streams drain before the buffers go back to the pool, whatever happened above
+            const hipError_t e1 = hipStreamSynchronize(ov->copy), e2 = hipStreamSynchronize(ov->compute);
+            SHP_TRY(rc);
+            SHP_HIP(e1); SHP_HIP(e2);
+        } else {
+            SHP_TRY(fused_disparity_dev(dl.as<float>(), dr.as<float>(), H, W, dmax, p, d_begin, d_end, ws.p, L.total,
+                                        keys.as<uint64_t>(), nullptr, nullptr));
+            SHP_TRY(finish_keys_to_host(keys.as<uint64_t>(), n, out_disp, out_cost));
+        }
         if (p->filter_kind == STEREO_FILTER_GUIDED && d_begin < d_end) {
             bool finite = true;
             SHP_TRY(guide_is_finite(static_cast<unsigned char *>(ws.p) + L.off_gmax, &finite));
