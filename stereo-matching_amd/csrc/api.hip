@@ -145,7 +145,9 @@ struct FusedWs {
     size_t words_bytes, plane_f64;
     size_t off_lw, off_rw, off_mean, off_invden, off_gmax, off_mm, total;
 };
-constexpr double FAST_KERNEL_MIN_EPS = 5e-3;
+// (8e-3: at 5e-3 two of 440 random frames were off by 1.1e-5 and 2.8e-5 of a cost unit where an overshoot next to a
+// run of `large` costs brings the filtered cost close to zero; from 6e-3 up the same frames are within 1e-6)
+constexpr double FAST_KERNEL_MIN_EPS = 8e-3;
 constexpr int FUSED_MAX_DISPARITIES = 65536;  // per launch; sizes the per-layer min/max scratch of the median path
 static FusedWs fused_ws_layout(int H, int W, int wct_radius) {
     FusedWs w;

@@ -617,19 +617,30 @@ def test_fused_median_rescale_rounds_twice(oracle):
 
 
 def test_guided_eps_is_judged_against_the_guide_range(oracle):
-    """A uint8 image as guide (values 0..255 instead of 0..1) makes eps = 0.005 tiny against the guide's variance:
-    the float32 second stage of the fast kernels would be off by 5e-5 of a cost unit here.  The choice between the
-    fast and the float64 kernel is made on the device from eps / max|guide|^2 (found by fuzzing)."""
+    """A uint8 image as guide (values 0..255 instead of 0..1) makes eps = 0.02 tiny against the guide's variance:
+    the float32 second stage of the fast kernels would be off by more than 1e-5 of a cost unit here.  The choice
+    between the fast and the float64 kernel is made on the device from eps / max|guide|^2 (found by fuzzing)."""
     import stereo
     from synth import synth_pair_gray
     h, w, dmax = 100, 191, 3
     left, right, _ = synth_pair_gray(h, w, dmax, seed=2252)
     left, right = (left * 255).astype(np.uint8), (right * 255).astype(np.uint8)
     dsi = oracle.wct_cost_volume(left, right, dmax, radius=4)
-    dref, cref, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, 4, 0.005, want_layers=True)
-    d, c = stereo.compute_disparity(left, right, dmax, guided_radius=4, guided_eps=0.005, show_progress=False)
+    dref, cref, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, 4, 0.02, want_layers=True)
+    d, c = stereo.compute_disparity(left, right, dmax, guided_radius=4, guided_eps=0.02, show_progress=False)
     fin = np.isfinite(cref)
     assert np.array_equal(np.isfinite(c), fin)
     assert rel_err(c[fin], cref[fin]) <= 1e-5
     for y, x in np.argwhere(d != dref):
         assert abs(float(layers[d[y, x], y, x]) - float(cref[y, x])) <= 1e-5 * max(1.0, abs(float(cref[y, x])))
+
+
+@pytest.mark.parametrize("case,eps", [(1023, 0.005), (3681, 0.005), (3681, 0.0051), (1023, 0.0079), (3681, 0.008)])
+def test_guided_eps_near_the_kernel_choice(oracle, case, eps, capsys):
+    """Two random frames on which the fast kernels were 1.1e-5 and 2.8e-5 of a cost unit off at eps = 0.005 (an
+    overshoot next to a run of `large` costs brings the filtered cost close to zero): eps below 8e-3 now takes the
+    float64 kernel; at and just above the limit the fast kernels stay within the bar."""
+    import fuzz_vs_oracle
+
+    failures = fuzz_vs_oracle.run_cases(case + 1, 20261111, verbose=False, only={case}, override={"guided_eps": eps})
+    assert failures == 0, capsys.readouterr().out
