@@ -96,6 +96,15 @@ __device__ __forceinline__ uint32_t shift_in_greater<float, uint32_t>(uint32_t w
     return out;
 }
 
+// 64-bit words: the carry ripples through the two halves.
+template <>
+__device__ __forceinline__ uint64_t shift_in_greater<float, uint64_t>(uint64_t word, float n, float c) {
+    uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32), out_lo, out_hi;
+    asm("v_cmp_gt_f32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %4, %4, vcc\n\tv_addc_co_u32 %1, vcc, %5, %5, vcc"
+        : "=&v"(out_lo), "=v"(out_hi) : "v"(n), "v"(c), "v"(lo), "v"(hi) : "vcc");
+    return ((uint64_t)out_hi << 32) | out_lo;
+}
+
 // One packed census word per pixel.  blockIdx.z selects the image, so the left and the right image
 // of a pair are packed by one launch.  The tile and its halo are staged in LDS with out-of-image
 // cells set to the lowest value; bits are shifted in from the most significant one down (direction 7
