@@ -65,6 +65,7 @@ __device__ __forceinline__ float ff_cost(const WordT *__restrict__ rw, const Cen
 // are paid once per 2048 pixels and disparity.  EXACT: the cost is an integer number of units
 // (field_sum) and is compared as such; `large` enters through a flag.
 constexpr int MM_ROWS = 4;
+constexpr int MM_CHUNK = 256;  // disparities whose per-wavefront results are parked in LDS between merges
 template <typename WordT, bool EXACT>
 __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restrict__ lw, const WordT *__restrict__ rw,
                                                          CensusCfg cfg, int H, int W, int d_begin, int d_end,
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restric
         }
     }
     const uint32_t large_key = f32_to_ordered(cfg.large);
-    for (int d = d_begin; d < d_end; ++d) {
+    // (min, max) of this wavefront's pixels for one disparity, reduced over the lanes
+    auto layer_range = [&](int d, uint32_t &lo_out, uint32_t &hi_out) {
         uint32_t lo = 0xffffffffu, hi = 0u;
         bool any_large = false;
 #pragma unroll
@@ -124,11 +126,35 @@ __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restric
             lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
             hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
         }
-        if (lane == 0) {
-            uint32_t *m = mm + 2 * (size_t)(d - d_begin);
+        lo_out = lo; hi_out = hi;
+    };
+    // The per-disparity results of a wavefront are parked in LDS and merged into the global table once per
+    // MM_CHUNK disparities by all lanes at once: the disparity loop then holds no global read-modify-write whose
+    // latency every iteration would have to wait for, and two disparities are evaluated per iteration so that
+    // twice as many loads are in flight.
+    __shared__ uint32_t parked[4][2][MM_CHUNK];
+    uint32_t (*mine)[MM_CHUNK] = parked[threadIdx.x >> 6];
+    for (int dc = d_begin; dc < d_end; dc += MM_CHUNK) {
+        const int n = min(MM_CHUNK, d_end - dc);
+        for (int i = 0; i < n; i += 2) {
+            uint32_t lo0, hi0, lo1 = 0xffffffffu, hi1 = 0u;
+            layer_range(dc + i, lo0, hi0);
+            if (i + 1 < n) layer_range(dc + i + 1, lo1, hi1);
+            if (lane == 0) {
+                mine[0][i] = lo0; mine[1][i] = hi0;
+                if (i + 1 < n) { mine[0][i + 1] = lo1; mine[1][i + 1] = hi1; }
+            }
+        }
+        // (the wavefront's own LDS writes are visible to its lanes after the wait the compiler places here)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = lane; i < n; i += 64) {
+            uint32_t *m = mm + 2 * (size_t)(dc + i - d_begin);
+            const uint32_t lo = mine[0][i], hi = mine[1][i];
             if (lo < m[0]) atomicMin(&m[0], lo);
             if (hi > m[1]) atomicMax(&m[1], hi);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
 }
 
