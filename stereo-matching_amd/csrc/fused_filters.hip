@@ -62,11 +62,11 @@ __device__ __forceinline__ float ff_cost(const WordT *__restrict__ rw, const Cen
 // ---- pass 1 (median only): min / max of every cost layer ---------------------------------------
 // One wavefront owns MM_ROWS rows x 512 columns: 8 x MM_ROWS pixels per lane whose left words stay in
 // registers over the disparity loop, so that the wavefront-wide reduction and the two global atomics
-// are paid once per 2048 pixels and disparity.  EXACT: the cost is an integer number of units
-// (field_sum) and is compared as such; `large` enters through a flag.
+// are paid once per 2048 pixels and disparity.  This version serves weights that are not exactly summable
+// (costs are float32 sums formed in the reference's order); cost_minmax_exact_kernel below serves the others.
 constexpr int MM_ROWS = 4;
 constexpr int MM_CHUNK = 256;  // disparities whose per-wavefront results are parked in LDS between merges
-template <typename WordT, bool EXACT>
+template <typename WordT>
 __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restrict__ lw, const WordT *__restrict__ rw,
                                                          CensusCfg cfg, int H, int W, int d_begin, int d_end,
                                                          uint32_t *__restrict__ mm) {
@@ -92,11 +92,9 @@ __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restric
             if (in && yvalid && xc >= R && xc < W - R) valid_bits |= 1u << (r * PPT + j);
         }
     }
-    const uint32_t large_key = f32_to_ordered(cfg.large);
     // (min, max) of this wavefront's pixels for one disparity, reduced over the lanes
     auto layer_range = [&](int d, uint32_t &lo_out, uint32_t &hi_out) {
         uint32_t lo = 0xffffffffu, hi = 0u;
-        bool any_large = false;
 #pragma unroll
         for (int r = 0; r < MM_ROWS; ++r) {
             const int ro = min(y0 + r, H - 1) * W;
@@ -105,21 +103,9 @@ __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restric
                 const int x = min(x0 + lane + 64 * j, W - 1);
                 const bool in = (inside_bits >> (r * PPT + j)) & 1u;
                 const bool ok = ((valid_bits >> (r * PPT + j)) & 1u) && x - d >= R;
-                if (EXACT) {
-                    const uint32_t u = field_sum((WordT)(lword[r][j] ^ rw[ro + (ok ? x - d : x)]));
-                    if (ok) { lo = min(lo, u); hi = max(hi, u); }
-                    any_large = any_large || (in && !ok);
-                } else {
-                    const uint32_t k = f32_to_ordered(ff_cost<WordT>(rw, cfg, lword[r][j], ok || ((valid_bits >> (r * PPT + j)) & 1u), ro, x, d));
-                    if (in) { lo = min(lo, k); hi = max(hi, k); }
-                }
+                const uint32_t k = f32_to_ordered(ff_cost<WordT>(rw, cfg, lword[r][j], ok || ((valid_bits >> (r * PPT + j)) & 1u), ro, x, d));
+                if (in) { lo = min(lo, k); hi = max(hi, k); }
             }
-        }
-        if (EXACT) {
-            // units -> order-preserving float keys; a lane without a valid pixel keeps the neutral elements
-            lo = lo == 0xffffffffu ? lo : f32_to_ordered((float)lo * cfg.unit);
-            hi = (lo == 0xffffffffu && hi == 0u) ? 0u : f32_to_ordered((float)hi * cfg.unit);
-            if (any_large) { lo = min(lo, large_key); hi = max(hi, large_key); }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -146,6 +132,114 @@ __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restric
             }
         }
         // (the wavefront's own LDS writes are visible to its lanes after the wait the compiler places here)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = lane; i < n; i += 64) {
+            uint32_t *m = mm + 2 * (size_t)(dc + i - d_begin);
+            const uint32_t lo = mine[0][i], hi = mine[1][i];
+            if (lo < m[0]) atomicMin(&m[0], lo);
+            if (hi > m[1]) atomicMax(&m[1], hi);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+}
+
+// The same pass for exactly summable weights (the cost is an integer number of units), written without
+// branches or per-pixel selects: validity travels as all-ones / all-zero masks, the column test x - d >= radius is
+// formed once per column and disparity, the rows of a wavefront are addressed through scalar base pointers,
+// and `large` enters through one flag per lane (a pixel inside the image costs `large` iff it is invalid for
+// every disparity -- known before the loop -- or its column fails the column test).
+template <typename WordT>
+__global__ __launch_bounds__(256) void cost_minmax_exact_kernel(const WordT *__restrict__ lw, const WordT *__restrict__ rw,
+                                                               CensusCfg cfg, int H, int W, int d_begin, int d_end,
+                                                               uint32_t *__restrict__ mm) {
+    constexpr int PPT = 8;  // pixels per lane and row: columns x0 + lane + 64 j
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int y0 = ((int)blockIdx.y * 4 + wave) * MM_ROWS;
+    const int x0 = blockIdx.x * (64 * PPT);
+    if (y0 >= H) return;
+    const int R = cfg.radius;
+    WordT lword[MM_ROWS][PPT];
+    uint32_t vmask[MM_ROWS][PPT];      // all ones: left census centre valid and the pixel inside the image
+    uint32_t col_inside[PPT];          // all ones: some row of the column lies inside the image
+    int xcol[PPT];
+    const WordT *rrow[MM_ROWS];
+    uint32_t const_large = 0u;         // all ones: some pixel of this lane is inside the image and never valid
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) { col_inside[j] = 0u; xcol[j] = min(x0 + lane + 64 * j, W - 1); }
+#pragma unroll
+    for (int r = 0; r < MM_ROWS; ++r) {
+        const int y = min(y0 + r, H - 1);
+        const bool yin = y0 + r < H, yvalid = y >= R && y < H - R;
+        rrow[r] = rw + (size_t)y * W;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int x = x0 + lane + 64 * j;
+            const bool in = yin && x < W;
+            const bool valid = in && yvalid && xcol[j] >= R && xcol[j] < W - R;
+            lword[r][j] = lw[(size_t)y * W + xcol[j]];
+            vmask[r][j] = valid ? 0xffffffffu : 0u;
+            if (in) col_inside[j] = 0xffffffffu;
+            if (in && !valid) const_large = 0xffffffffu;
+        }
+    }
+    // the masks live in vector registers from here on (left to itself the compiler turns them back into lane
+    // masks in scalar registers, runs out of those, and spills them through v_writelane / v_readlane)
+#pragma unroll
+    for (int r = 0; r < MM_ROWS; ++r)
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) asm volatile("" : "+v"(vmask[r][j]));
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) asm volatile("" : "+v"(col_inside[j]));
+    asm volatile("" : "+v"(const_large));
+    const uint32_t large_key = f32_to_ordered(cfg.large);
+    auto layer_range = [&](int d, uint32_t &lo_out, uint32_t &hi_out) {
+        uint32_t lo = 0xffffffffu, hi = 0u, large_seen = const_large;
+        uint32_t okx[PPT], boff[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int t = xcol[j] - d;
+            okx[j] = (uint32_t)((R - 1 - t) >> 31);                    // all ones iff t >= R
+            boff[j] = (uint32_t)max(t, 0) * (uint32_t)sizeof(WordT);   // (a column that fails the test reads any word)
+            large_seen |= col_inside[j] & ~okx[j];
+        }
+#pragma unroll
+        for (int r = 0; r < MM_ROWS; ++r) {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const WordT rword = *reinterpret_cast<const WordT *>(reinterpret_cast<const char *>(rrow[r]) + boff[j]);
+                const uint32_t u = field_sum((WordT)(lword[r][j] ^ rword));
+                const uint32_t m = vmask[r][j] & okx[j];
+                lo = min(lo, u | ~m);
+                hi = max(hi, u & m);
+            }
+        }
+        // units -> order-preserving float keys; a lane without a valid pixel keeps the neutral elements
+        const bool none = lo == 0xffffffffu;
+        lo = none ? lo : f32_to_ordered((float)lo * cfg.unit);
+        hi = (none && hi == 0u) ? 0u : f32_to_ordered((float)hi * cfg.unit);
+        if (large_seen) { lo = min(lo, large_key); hi = max(hi, large_key); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+        }
+        lo_out = lo; hi_out = hi;
+    };
+    __shared__ uint32_t parked[4][2][MM_CHUNK];
+    uint32_t (*mine)[MM_CHUNK] = parked[wave];
+    for (int dc = d_begin; dc < d_end; dc += MM_CHUNK) {
+        const int n = min(MM_CHUNK, d_end - dc);
+        for (int i = 0; i < n; i += 2) {
+            uint32_t lo0, hi0, lo1 = 0xffffffffu, hi1 = 0u;
+            layer_range(dc + i, lo0, hi0);
+            if (i + 1 < n) layer_range(dc + i + 1, lo1, hi1);
+            if (lane == 0) {
+                mine[0][i] = lo0; mine[1][i] = hi0;
+                if (i + 1 < n) { mine[0][i + 1] = lo1; mine[1][i + 1] = hi1; }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int i = lane; i < n; i += 64) {
@@ -566,11 +660,11 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
             dim3 grid(ceil_div(W, 64 * 8), ceil_div(H, 4 * MM_ROWS));
             const bool exact = cfg.exact && cfg.unit > 0.f;
             if (cfg.word64) {
-                auto kern = exact ? cost_minmax_kernel<uint64_t, true> : cost_minmax_kernel<uint64_t, false>;
+                auto kern = exact ? cost_minmax_exact_kernel<uint64_t> : cost_minmax_kernel<uint64_t>;
                 hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, static_cast<const uint64_t *>(d_lw),
                                    static_cast<const uint64_t *>(d_rw), cfg, H, W, d_begin, d_end, d_mm);
             } else {
-                auto kern = exact ? cost_minmax_kernel<uint32_t, true> : cost_minmax_kernel<uint32_t, false>;
+                auto kern = exact ? cost_minmax_exact_kernel<uint32_t> : cost_minmax_kernel<uint32_t>;
                 hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, static_cast<const uint32_t *>(d_lw),
                                    static_cast<const uint32_t *>(d_rw), cfg, H, W, d_begin, d_end, d_mm);
             }
