@@ -55,6 +55,32 @@ def main() -> None:
             worst_wall, worst_kernel = max(worst_wall, wall), max(worst_kernel, ms.value / max(n.value, 1))
         print(f"N={world}: slowest shard {worst_wall:.3f} ms per step (fused kernel {worst_kernel:.3f} ms)", flush=True)
 
+    # rows x disparities: a rank searches a horizontal part of the frame (cut on tile rows, one tile row of halo on
+    # each inner side, so that its tiles coincide with the whole frame's) for a contiguous disparity range
+    th = 30
+    tile_rows = -(-H // th)
+    for ry, rd in ((2, 4), (4, 2), (8, 1), (2, 2), (2, 1)):
+        worst = 0.0
+        for iy in range(ry):
+            t0r, t1r = iy * tile_rows // ry, (iy + 1) * tile_rows // ry
+            row0, row1 = max(0, (t0r - 1) * th), min(H, (t1r + 1) * th)
+            for idd in range(rd):
+                d0, d1 = sharding.shard_range(D, rd, idd)
+
+                def run():
+                    _native.check(lib.stereo_compute_disparity_dev(left.data_ptr() + row0 * W * 4, right.data_ptr() + row0 * W * 4,
+                                                                   row1 - row0, W, D, params, d0, d1, ws.data_ptr(),
+                                                                   ws_bytes.value, keys.data_ptr(), stream))
+                for _ in range(2):
+                    run()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    run()
+                torch.cuda.synchronize()
+                worst = max(worst, (time.perf_counter() - t0) / 10 * 1e3)
+        print(f"N={ry * rd} as {ry} row parts x {rd} disparity ranges: slowest shard {worst:.3f} ms per step", flush=True)
+
 
 if __name__ == "__main__":
     main()
