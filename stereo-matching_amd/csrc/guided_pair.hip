@@ -29,9 +29,6 @@ template <typename WordT>
 struct PairLds {
     double *mG;      // [NJ][128] box mean of the guide
     uint64_t *key;   // [TH][128] packed (cost, d)
-    double *iay1;    // [NJ] 1 / (rows of the clipped window), 0 outside the image
-    float *cy2;      // [TH] rows of the clipped window of the output rows (0 outside the image)
-    double *invtab;  // [16] 1/n
     WordT *L;        // [NI][128] left census words
     float *inv;      // [NJ][128] 1 / ((var + eps) * window area)
     float *glo;      // [NI][128] guide - k * 2^-s
@@ -39,6 +36,23 @@ struct PairLds {
     int *next_d;     // [0] next disparity to hand out, [1] lowest disparity whose costs are all `large`
     short *k;        // [NI][128] round(guide * 2^s)
 };
+
+// 1 / n for the window lengths a clipped box filter can have (n = 0: outside the image).  Row counts are the
+// same for every lane, so these are scalar loads; the table replaces three small LDS arrays.
+__constant__ double pair_inv_n[16] = {0.0,       1.0,       1.0 / 2.0,  1.0 / 3.0,  1.0 / 4.0,  1.0 / 5.0,  1.0 / 6.0,  1.0 / 7.0,
+                                      1.0 / 8.0, 1.0 / 9.0, 1.0 / 10.0, 1.0 / 11.0, 1.0 / 12.0, 1.0 / 13.0, 1.0 / 14.0, 1.0 / 15.0};
+// rows (or columns) of the radius-r window centred on `y` that lie inside [0, n); 0 when y itself is outside
+__device__ __forceinline__ int clipped_len(int y, int r, int n) {
+    return (y >= 0 && y < n) ? min(y + r, n - 1) - max(y - r, 0) + 1 : 0;
+}
+// t / area, exact whenever the quotient is representable (one Newton step on the hardware reciprocal), so that a
+// window of equal costs returns that cost; an infinite sum (the initial key) stays infinite
+__device__ __forceinline__ float mean_from_sum(float t, float area) {
+    const float r0 = __builtin_amdgcn_rcpf(area);
+    const float q0 = t * r0;
+    const float q = fmaf(fmaf(-q0, area, t), r0, q0);
+    return fabsf(t) <= 3.0e38f ? q : t;
+}
 
 template <typename T>
 using Pair = T __attribute__((ext_vector_type(2)));  // the two slots of a lane, loaded with one LDS read
@@ -112,20 +126,14 @@ __device__ __forceinline__ void pair_disparity_pass(
         return INTERIOR ? y : min(max(y, 0), H - 1);
     };
     double ia_interior[2];
-    float area_interior[2], rcp_interior[2];
+    float area_interior[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         ia_interior[j] = pl.invAX1[j] * (1.0 / (double)WIN);
         area_interior[j] = pl.cxf[j] * (float)WIN;
-        rcp_interior[j] = __builtin_amdgcn_rcpf(area_interior[j]);
     }
-    // full windows: the same reciprocal instruction as the other modes use, on a value the
-    // compiler cannot fold, so that every mode rounds a pixel's quotient identically
-    float area_full = (float)(WIN * WIN);
-    asm volatile("" : "+v"(area_full));
-    const float rcp_full = __builtin_amdgcn_rcpf(area_full);
-    const f2 area_mode = LEAN ? f2{area_full, area_full} : f2{area_interior[0], area_interior[1]};
-    const f2 rcp_mode = LEAN ? f2{rcp_full, rcp_full} : f2{rcp_interior[0], rcp_interior[1]};
+    const f2 area_mode = LEAN ? f2{(float)(WIN * WIN), (float)(WIN * WIN)} : f2{area_interior[0], area_interior[1]};
+    auto cy2_of_row = [&](int y) -> float { return (float)clipped_len(y, RG, H); };
     constexpr double ia_full = 1.0 / (double)(WIN * WIN);
 
     // Operands of a row are fetched one row ahead; the head of the next row is carried from one
@@ -168,8 +176,6 @@ __device__ __forceinline__ void pair_disparity_pass(
         LDS_AS const float *invg1 = lds_lane_ptr(t.inv + (base - HALO) * TC + pl.c1b);
         LDS_AS const Pair<float> *goutg = lds_lane_ptr(reinterpret_cast<const Pair<float> *>(t.gout + (base - 2 * HALO) * TC + 2 * lane));
         LDS_AS uint64_t *keyg = lds_lane_ptr(t.key + (base - 2 * HALO) * TC + lane);
-        LDS_AS const double *iay1g = lds_lane_ptr(t.iay1 + (base - HALO));
-        LDS_AS const float *cy2g = lds_lane_ptr(t.cy2 + (base - 2 * HALO));
         auto fetch_head = [&](int k) {
             RowHead r;
             const Pair<WordT> lp = Lg[k * (TC / 2)];
@@ -265,7 +271,8 @@ __device__ __forceinline__ void pair_disparity_pass(
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const double ia = LEAN ? ia_full : INTERIOR ? ia_interior[j] : iay1g[k] * pl.invAX1[j];
+                    const double ia = LEAN ? ia_full : INTERIOR ? ia_interior[j]
+                                                     : pair_inv_n[clipped_len(ty0 - HALO + i - RG, RG, H)] * pl.invAX1[j];
                     const double s1d = (double)s1[j];
                     const double u = fma(-mG[j], s1d, fma((double)si[j], inv_scale_d, (double)sf[j]));
                     const double av = u * (double)inv_f[j];
@@ -306,29 +313,24 @@ __device__ __forceinline__ void pair_disparity_pass(
                     f2 dsum;
                     dsum.x = fmaf(av[RG].x, gp[0].x - gp[RG].x, acc0.x + acc0.y);
                     dsum.y = acc1.x + acc1.y;
-                    // 7. q and the running WTA
+                    // 7. the running WTA.  The key carries the window SUM t32, not the mean: for one pixel the
+                    //    window area is the same at every disparity, so the order of the sums is the order of
+                    //    the means, equal sums are equal means, and the division is done once per pixel when
+                    //    the tile's keys are written out instead of once per disparity.
                     const f2 t32 = se + dsum;
-                    f2 areav, r0v;
-                    if (INTERIOR) {
-                        areav = area_mode; r0v = rcp_mode;
-                    } else {
-                        const float cy = cy2g[k];
-                        areav = f2{cy * pl.cxf[0], cy * pl.cxf[1]};
-                        r0v = f2{__builtin_amdgcn_rcpf(areav.x), __builtin_amdgcn_rcpf(areav.y)};
-                    }
-                    const f2 q0 = t32 * r0v;
-                    const f2 qv = fma2(fma2(-q0, areav, t32), r0v, q0) * f2{a.unit, a.unit};
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        float qf = qv[j];
+                        float tf = t32[j];
                         if (QOUT) {
                             const int yo = ty0 + o;
                             const int tc = 2 * lane + j;
-                            if (tc >= HALO && tc < TC - HALO && pl.x[j] < W && yo < H)
-                                a.q_out[((size_t)d * H + yo) * W + pl.x[j]] = qf;
+                            if (tc >= HALO && tc < TC - HALO && pl.x[j] < W && yo < H) {
+                                const float areaf = INTERIOR ? area_mode[j] : cy2_of_row(yo) * pl.cxf[j];
+                                a.q_out[((size_t)d * H + yo) * W + pl.x[j]] = mean_from_sum(tf, areaf) * a.unit;
+                            }
                         }
-                        if (!LEAN) qf = (qf == qf) ? qf : __int_as_float(0x7f800000);
-                        const unsigned long long key = ((unsigned long long)ordered_bits(qf) << 32) | (uint32_t)d;
+                        if (!LEAN) tf = (tf == tf) ? tf : __int_as_float(0x7f800000);
+                        const unsigned long long key = ((unsigned long long)ordered_bits(tf) << 32) | (uint32_t)d;
                         __hip_atomic_fetch_min(reinterpret_cast<LDS_AS unsigned long long *>(keyg + k * TC + j * 64), key,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -387,9 +389,6 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
     PairLds<WordT> t;
     t.mG = reinterpret_cast<double *>(sp); sp += sizeof(double) * NJ * TC;
     t.key = reinterpret_cast<uint64_t *>(sp); sp += sizeof(uint64_t) * TH * TC;
-    t.iay1 = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((NJ + 1) / 2 * 2);
-    t.cy2 = reinterpret_cast<float *>(sp); sp += sizeof(double) * ((TH + 1) / 2 * 2);
-    t.invtab = reinterpret_cast<double *>(sp); sp += sizeof(double) * 16;
     t.L = reinterpret_cast<WordT *>(sp); sp += sizeof(WordT) * NI * TC;
     t.inv = reinterpret_cast<float *>(sp); sp += sizeof(float) * NJ * TC;
     t.glo = reinterpret_cast<float *>(sp); sp += sizeof(float) * NI * TC;
@@ -488,15 +487,6 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
     if (!finite_in) t.next_d[2] = 1;  // (after the barrier below it reads 0 unless some thread saw a non-finite input)
     for (int idx = threadIdx.x; idx < TH * TC; idx += NW * 64) t.key[idx] = SHP_KEY_INIT;
     if (threadIdx.x < 16) t.gout[TH * TC + threadIdx.x] = 0.f;
-    for (int j = threadIdx.x; j < NJ; j += NW * 64) {
-        int y = ty0 - RG + j;
-        t.iay1[j] = (y >= 0 && y < H) ? 1.0 / (double)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.0;
-    }
-    for (int o = threadIdx.x; o < TH; o += NW * 64) {
-        int y = ty0 + o;
-        t.cy2[o] = (y < H) ? (float)(min(y + RG, H - 1) - max(y - RG, 0) + 1) : 0.f;
-    }
-    if (threadIdx.x <= WIN) t.invtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
     __syncthreads();
 
     const int R = a.radius;
@@ -513,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         pl.x[j] = x;
         pl.x_in[j] = x_in;
         pl.x_valid[j] = x_in && x >= R && x < W - R;
-        pl.invAX1[j] = t.invtab[cx1];
+        pl.invAX1[j] = pair_inv_n[cx1];
         pl.cxf[j] = (float)cx;
     }
     pl.c1 = deint(max(2 * lane - RG, 0));
@@ -552,6 +542,12 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         int gy = ty0 + o, gx = tx0 - HALO + c;
         if (c >= HALO && c < TC - HALO && gy < H && gx < W) {
             uint64_t key = t.key[o * TC + deint(c)];
+            {
+                // the tile's keys hold window sums: the mean (and the cost unit) enter here, once per pixel
+                const float area = (float)(clipped_len(gy, RG, H) * clipped_len(gx, RG, W));
+                const float q = mean_from_sum(ordered_to_f32((uint32_t)(key >> 32)), area) * a.unit;
+                key = ((uint64_t)f32_to_ordered(q) << 32) | (key & 0xffffffffu);
+            }
             if (skipped_d != 0x7fffffff) {
                 const uint64_t kl = make_key(large_f, (uint32_t)skipped_d);
                 key = kl < key ? kl : key;
@@ -591,8 +587,7 @@ template <int RG, bool WORD64>
 struct PairTile {
     static constexpr size_t bytes(int th) {
         const size_t ni = th + 4 * RG, nj = th + 2 * RG, tc = 128, w = WORD64 ? 8 : 4;
-        return sizeof(double) * nj * tc + sizeof(uint64_t) * th * tc + sizeof(double) * ((nj + 1) / 2 * 2) +
-               sizeof(double) * ((th + 1) / 2 * 2) + sizeof(double) * 16 + w * ni * tc + sizeof(float) * nj * tc +
+        return sizeof(double) * nj * tc + sizeof(uint64_t) * th * tc + w * ni * tc + sizeof(float) * nj * tc +
                sizeof(float) * ni * tc + sizeof(float) * (th * tc + 16) + 16 + sizeof(short) * (ni + 1) * tc;  // one pad row: rows are fetched one ahead
     }
     static constexpr int best() {
