@@ -30,7 +30,7 @@ struct PairLds {
     double *mG;      // [NJ][128] box mean of the guide
     uint64_t *key;   // [TH][128] packed (cost, d)
     WordT *L;        // [NI][128] left census words
-    float *inv;      // [NJ][128] 1 / ((var + eps) * window area)
+    float *inv;      // [NJ][128] cost unit / ((var + eps) * window area): a and b come out in cost units
     float *glo;      // [NI][128] guide - k * 2^-s
     float *gout;     // [TH][128] (+pad) guide at the output pixels
     int *next_d;     // [0] next disparity to hand out, [1] lowest disparity whose costs are all `large`
@@ -45,15 +45,6 @@ __constant__ double pair_inv_n[16] = {0.0,       1.0,       1.0 / 2.0,  1.0 / 3.
 __device__ __forceinline__ int clipped_len(int y, int r, int n) {
     return (y >= 0 && y < n) ? min(y + r, n - 1) - max(y - r, 0) + 1 : 0;
 }
-// t / area, exact whenever the quotient is representable (one Newton step on the hardware reciprocal), so that a
-// window of equal costs returns that cost; an infinite sum (the initial key) stays infinite
-__device__ __forceinline__ float mean_from_sum(float t, float area) {
-    const float r0 = __builtin_amdgcn_rcpf(area);
-    const float q0 = t * r0;
-    const float q = fmaf(fmaf(-q0, area, t), r0, q0);
-    return fabsf(t) <= 3.0e38f ? q : t;
-}
-
 template <typename T>
 using Pair = T __attribute__((ext_vector_type(2)));  // the two slots of a lane, loaded with one LDS read
 // The float32 arithmetic of the two slots is written on pairs: with two wavefronts per SIMD every
@@ -71,7 +62,7 @@ struct PairLane {
     int x[2];             // image column of the slot's cost and of its final output
     bool x_in[2];         // column inside the image
     bool x_valid[2];      // census centre valid in x
-    double invAX1[2];     // 1 / (columns of the clipped stage-1 window), 0 outside the image
+    double invAX1[2];     // cost unit / (columns of the clipped stage-1 window), 0 outside the image
     float cxf[2];         // columns of the clipped output window
     int c1, c1b;          // de-interleaved positions of the stage-1 columns of slot 0 and slot 1 (clamped to >= 0)
 };
@@ -126,15 +117,16 @@ __device__ __forceinline__ void pair_disparity_pass(
         return INTERIOR ? y : min(max(y, 0), H - 1);
     };
     double ia_interior[2];
-    float area_interior[2];
+    float area_interior[2], rcp_interior[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        ia_interior[j] = pl.invAX1[j] * (1.0 / (double)WIN);
+        ia_interior[j] = pl.invAX1[j] * (1.0 / (double)WIN);   // (invAX1 carries the cost unit)
         area_interior[j] = pl.cxf[j] * (float)WIN;
+        rcp_interior[j] = __builtin_amdgcn_rcpf(area_interior[j]);
     }
-    const f2 area_mode = LEAN ? f2{(float)(WIN * WIN), (float)(WIN * WIN)} : f2{area_interior[0], area_interior[1]};
-    auto cy2_of_row = [&](int y) -> float { return (float)clipped_len(y, RG, H); };
-    constexpr double ia_full = 1.0 / (double)(WIN * WIN);
+    const f2 area_mode = f2{area_interior[0], area_interior[1]};
+    const f2 rcp_mode = f2{rcp_interior[0], rcp_interior[1]};
+    const double ia_full = (double)a.unit * (1.0 / (double)(WIN * WIN));
 
     // Operands of a row are fetched one row ahead; the head of the next row is carried from one
     // row group into the next so that no group starts by waiting for its own loads.
@@ -313,21 +305,36 @@ __device__ __forceinline__ void pair_disparity_pass(
                     f2 dsum;
                     dsum.x = fmaf(av[RG].x, gp[0].x - gp[RG].x, acc0.x + acc0.y);
                     dsum.y = acc1.x + acc1.y;
-                    // 7. the running WTA.  The key carries the window SUM t32, not the mean: for one pixel the
-                    //    window area is the same at every disparity, so the order of the sums is the order of
-                    //    the means, equal sums are equal means, and the division is done once per pixel when
-                    //    the tile's keys are written out instead of once per disparity.
+                    // 7. q and the running WTA.  a and b already carry the cost unit.  Full windows: one multiply by
+                    //    fl(1 / (2r+1)^2), whose relative error is below 2^-25 for r = 1..4, so a window of equal
+                    //    costs c (t32 = (2r+1)^2 c exactly) rounds to exactly c; clipped windows: one Newton step on
+                    //    the reciprocal, exact whenever the quotient is representable.  Either way constant `large`
+                    //    windows stay exact ties.
                     const f2 t32 = se + dsum;
+                    f2 qv;
+                    if (LEAN) {
+                        constexpr float rcp_full = 1.0f / (float)(WIN * WIN);
+                        qv = t32 * f2{rcp_full, rcp_full};
+                    } else {
+                        f2 areav, r0v;
+                        if (INTERIOR) {
+                            areav = area_mode; r0v = rcp_mode;
+                        } else {
+                            const float cy = (float)clipped_len(ty0 + o, RG, H);
+                            areav = f2{cy * pl.cxf[0], cy * pl.cxf[1]};
+                            r0v = f2{__builtin_amdgcn_rcpf(areav.x), __builtin_amdgcn_rcpf(areav.y)};
+                        }
+                        const f2 q0 = t32 * r0v;
+                        qv = fma2(fma2(-q0, areav, t32), r0v, q0);
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        float tf = t32[j];
+                        float tf = qv[j];
                         if (QOUT) {
                             const int yo = ty0 + o;
                             const int tc = 2 * lane + j;
-                            if (tc >= HALO && tc < TC - HALO && pl.x[j] < W && yo < H) {
-                                const float areaf = INTERIOR ? area_mode[j] : cy2_of_row(yo) * pl.cxf[j];
-                                a.q_out[((size_t)d * H + yo) * W + pl.x[j]] = mean_from_sum(tf, areaf) * a.unit;
-                            }
+                            if (tc >= HALO && tc < TC - HALO && pl.x[j] < W && yo < H)
+                                a.q_out[((size_t)d * H + yo) * W + pl.x[j]] = tf;
                         }
                         if (!LEAN) tf = (tf == tf) ? tf : __int_as_float(0x7f800000);
                         const unsigned long long key = ((unsigned long long)ordered_bits(tf) << 32) | (uint32_t)d;
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
             const double mg = in ? m_in[u] : 0.0;
             t.mG[j * TC + deint(c)] = mg;
             const int cyy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1, cxx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
-            const float iv = in ? (float)(d_in[u] / (double)(cyy * cxx)) : 0.f;
+            const float iv = in ? (float)(d_in[u] * (double)a.unit / (double)(cyy * cxx)) : 0.f;
             t.inv[j * TC + deint(c)] = iv;
             finite_in = finite_in && fabs(mg) <= 1.0e300 && fabsf(iv) <= 3.0e38f;
         }
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         pl.x[j] = x;
         pl.x_in[j] = x_in;
         pl.x_valid[j] = x_in && x >= R && x < W - R;
-        pl.invAX1[j] = pair_inv_n[cx1];
+        pl.invAX1[j] = pair_inv_n[cx1] * (double)a.unit;
         pl.cxf[j] = (float)cx;
     }
     pl.c1 = deint(max(2 * lane - RG, 0));
@@ -542,12 +549,6 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         int gy = ty0 + o, gx = tx0 - HALO + c;
         if (c >= HALO && c < TC - HALO && gy < H && gx < W) {
             uint64_t key = t.key[o * TC + deint(c)];
-            {
-                // the tile's keys hold window sums: the mean (and the cost unit) enter here, once per pixel
-                const float area = (float)(clipped_len(gy, RG, H) * clipped_len(gx, RG, W));
-                const float q = mean_from_sum(ordered_to_f32((uint32_t)(key >> 32)), area) * a.unit;
-                key = ((uint64_t)f32_to_ordered(q) << 32) | (key & 0xffffffffu);
-            }
             if (skipped_d != 0x7fffffff) {
                 const uint64_t kl = make_key(large_f, (uint32_t)skipped_d);
                 key = kl < key ? kl : key;
