@@ -97,20 +97,20 @@ __device__ __forceinline__ void pair_disparity_pass(
         roff[j] = (unsigned)min(max(pl.x[j] - d, 0), W - 1) * (unsigned)sizeof(WordT);
     }
 
+    // 32-bit census words (radius <= 4): a cost is at most 1200 units, so the vertical sums (<= 8400) and the
+    // window sums (<= 58800) of the two slots share one register, 16 bits each: half the adds and lane shifts.
+    constexpr bool PACK16 = !WORD64;
     uint32_t C1[2] = {0u, 0u};
+    uint32_t C1p = 0u, prp[WIN];
     int I2[2] = {0, 0};
     f2 F2 = {0.f, 0.f};
     double A[2] = {0.0, 0.0}, B[2] = {0.0, 0.0};
+    // rings of the rows inside the two vertical windows; a slot is first read one window length after it was
+    // first written (the start-up row groups below are peeled and skip the retiring step), so none is cleared
     uint32_t pr[2][WIN];
     int kr[2][WIN];
     f2 gr[WIN];
     double ar[2][WIN], br[2][WIN];
-#pragma unroll
-    for (int k = 0; k < WIN; ++k) gr[k] = f2{0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int k = 0; k < WIN; ++k) { pr[j][k] = 0u; kr[j][k] = 0; ar[j][k] = 0.0; br[j][k] = 0.0; }
 
     auto row_of = [&](int i) -> int {
         int y = ty0 - HALO + i;
@@ -196,13 +196,17 @@ __device__ __forceinline__ void pair_disparity_pass(
             for (int u = 0; u <= RG; ++u) gp[u] = goutg[k * (TC / 2) + u];
             // 2a. the row leaving the window [i - 2r, i] retires first, so that its ring registers are
             //     free before the new row's values are formed (no register copies at the loop edge)
+            if (STEADY || i >= WIN) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                C1[j] -= pr[j][k];
-                I2[j] -= kr[j][k];
+                for (int j = 0; j < 2; ++j) {
+                    if (!PACK16) C1[j] -= pr[j][k];
+                    I2[j] -= kr[j][k];
+                }
+                if (PACK16) C1p -= prp[k];
+                F2 -= gr[k];
             }
-            F2 -= gr[k];
             f2 pf;
+            uint32_t pq[2];
             // 1. costs in units; k*p and g_lo*p; 2b. the new row enters the vertical running sums
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -221,9 +225,15 @@ __device__ __forceinline__ void pair_disparity_pass(
                 int kp = __mul24(cur.k[j], (int)p);
                 asm volatile("" : "+v"(kp));  // one multiply: the running sum adds kp instead of re-deriving it
                 pf[j] = (float)p;
-                C1[j] += p;
+                if (!PACK16) { C1[j] += p; pr[j][k] = p; }
                 I2[j] += kp;
-                pr[j][k] = p; kr[j][k] = kp;
+                kr[j][k] = kp;
+                pq[j] = p;
+            }
+            if (PACK16) {
+                const uint32_t pp = pq[0] | (pq[1] << 16);
+                C1p += pp;
+                prp[k] = pp;
             }
             {
                 const f2 gl = cur.glo * pf;
@@ -233,33 +243,50 @@ __device__ __forceinline__ void pair_disparity_pass(
             if (STEADY || i >= HALO) {
                 // 3. sums over the 2r + 1 columns ending in each slot: the box sums of column x - r
                 uint32_t e1 = C1[0], o1 = C1[1], e1r = C1[0], o1r = C1[1];
+                uint32_t cp = C1p, cpr = C1p;
                 int ei = I2[0], oi = I2[1], eir = I2[0], oir = I2[1];
                 float ef_ = F2.x, of_ = F2.y, efr = F2.x, ofr = F2.y;
 #pragma unroll
                 for (int u = 0; u < RG; ++u) {
                     e1r = e1; o1r = o1; eir = ei; oir = oi; efr = ef_; ofr = of_;   // partial sums of u + 1 lanes
-                    e1 = C1[0] + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)e1);
-                    o1 = C1[1] + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)o1);
+                    if (PACK16) {
+                        cpr = cp;
+                        cp = C1p + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)cp);
+                    } else {
+                        e1 = C1[0] + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)e1);
+                        o1 = C1[1] + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)o1);
+                    }
                     ei = I2[0] + dpp_i<DPP_WAVE_SHR1>(ei);
                     oi = I2[1] + dpp_i<DPP_WAVE_SHR1>(oi);
                     ef_ = F2.x + dpp_f<DPP_WAVE_SHR1>(ef_);
                     of_ = F2.y + dpp_f<DPP_WAVE_SHR1>(of_);
                 }
+                // (the integer partial sums are pinned: re-associated, each three-operand add would need its
+                //  lane-shifted operands as separate move instructions)
+                asm volatile("" : "+v"(e1), "+v"(o1), "+v"(ei), "+v"(oi), "+v"(cp));
                 uint32_t s1[2];
                 int si[2];
                 float sf[2];
-                s1[0] = e1 + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)o1r);
+                if (PACK16) {
+                    const uint32_t tp = (uint32_t)__builtin_amdgcn_mov_dpp((int)cpr, DPP_WAVE_SHR1, 0xf, 0xf, true);
+                    s1[0] = (cp & 0xffffu) + (tp >> 16);
+                    s1[1] = (cp >> 16) + (cpr & 0xffffu);
+                } else {
+                    s1[0] = e1 + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)o1r);
+                    s1[1] = o1 + e1r;
+                }
                 si[0] = ei + dpp_i<DPP_WAVE_SHR1>(oir);
                 sf[0] = ef_ + dpp_f<DPP_WAVE_SHR1>(ofr);
-                s1[1] = o1 + e1r;
                 si[1] = oi + eir;
                 sf[1] = of_ + efr;
                 // 4. a, b; 5. their vertical running sums over stage-1 rows [j - 2r, j]
                 const int k2 = (k + 1) % WIN;
+                if (STEADY || i >= HALO + WIN) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    A[j] -= ar[j][k2];
-                    B[j] -= br[j][k2];
+                    for (int j = 0; j < 2; ++j) {
+                        A[j] -= ar[j][k2];
+                        B[j] -= br[j][k2];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
