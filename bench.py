@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the dense-stereo hot path (fused WCT cost -> guided filter -> WTA) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload motorcycle|4k]
+    python bench.py --gpus N --steps K --warmup W [--workload motorcycle|4k|8k] [--filter ...] [--path fused|two-call]
 
 One "step" is one full pass of the hot path over one synthetic stereo pair that is already
 resident in HBM: census packing of both images, guide statistics, the fused
@@ -10,6 +10,13 @@ cost+filter+WTA kernel over the rank's disparity shard, and (N > 1) the per-pixe
 
 For N > 1 the launcher is torch.distributed.run (one rank per GPU); the disparity range is
 split evenly over the ranks, the images are replicated (total work is fixed: strong scaling).
+
+A run whose sharded result differs from the unsharded one, or in which a row-band wait timed out, is a
+FAILED run: the line carries "value": null and an "error" text, and every rank exits with status 1.
+
+--path two-call times the reference's two-call data flow on device buffers instead of the fused kernel:
+compute_wct_cost_volume writes the float32 cost volume to HBM (census.py:250) and aggregate_and_wta reads
+it back (stereo.py:146); there the algorithmic bytes are real bytes.
 """
 from __future__ import annotations
 
@@ -41,19 +48,33 @@ FILTERS = {"guided": "FILTER_GUIDED", "median": "FILTER_MEDIAN_U8Q", "gaussian":
            "bilateral": "FILTER_BILATERAL"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
 # per-launch counter averages of a `rocprofv3 --pmc` run of this same command (tools/pmc_passes.sh)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "pair_pmc_per_launch.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pair_pmc_per_launch.json")
 DOMINANT_KERNEL = "fused_guided_pair_kernel"
 
 
-def measured_hbm_traffic(workload: str):
-    """HBM bytes per launch of the dominant kernel from the committed counter summary: FETCH_SIZE and
-    WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes read.  None when the
-    summary is missing or was not taken on this workload."""
+def _pmc_summary(workload: str, library_version: str):
+    """The committed counter summary, or None when it is missing, was not taken on this workload or was taken
+    on another build of the library (its "__library_version__" entry must equal stereo_hip_version())."""
     if workload != "motorcycle" or not os.path.exists(PMC_SUMMARY):
         return None
     try:
         with open(PMC_SUMMARY) as fh:
             summary = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if summary.get("__library_version__") != library_version:
+        return None
+    return {k: v for k, v in summary.items() if isinstance(v, dict)}
+
+
+def measured_hbm_traffic(workload: str, library_version: str):
+    """HBM bytes per launch of the dominant kernel from the committed counter summary: FETCH_SIZE and
+    WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes read.  None when no summary of
+    this build and workload exists."""
+    summary = _pmc_summary(workload, library_version)
+    if summary is None:
+        return None
+    try:
         for name, counters in summary.items():
             if DOMINANT_KERNEL in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
                 return int((2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0)
@@ -62,15 +83,14 @@ def measured_hbm_traffic(workload: str):
     return None
 
 
-def counter_ratios(workload: str):
+def counter_ratios(workload: str, library_version: str):
     """LDS bank-conflict rate and vector-ALU busy fraction of the dominant kernel from the same committed
     counter summary (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; SQ_ACTIVE_INST_VALU * 4 / SIMDs / GRBM_GUI_ACTIVE
     with both counters summed over the eight XCDs, 1024 SIMDs)."""
-    if workload != "motorcycle" or not os.path.exists(PMC_SUMMARY):
+    summary = _pmc_summary(workload, library_version)
+    if summary is None:
         return None, None
     try:
-        with open(PMC_SUMMARY) as fh:
-            summary = json.load(fh)
         for name, c in summary.items():
             if DOMINANT_KERNEL in name:
                 lds = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None
@@ -102,8 +122,13 @@ def parse_args():
     ap.add_argument("--filter", choices=sorted(FILTERS), default="guided",
                     help="aggregation filter (median = the reference's default uint8-quantised method, radius 3; "
                          "gaussian / bilateral sigma 1)")
-    ap.add_argument("--cpu-rows", type=int, default=600, help="rows of the workload the CPU baseline is timed on")
+    ap.add_argument("--path", choices=["fused", "two-call"], default="fused",
+                    help="fused: the volume-free kernel (default); two-call: cost volume written to HBM, then aggregated")
+    ap.add_argument("--cpu-rows", type=int, default=0,
+                    help="rows of the workload the CPU baseline is timed on (0 = every row: the whole frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true",
+                    help="skip the second CPU figure (layers dealt to every core instead of the reference's threading)")
     ap.add_argument("--bands", type=int, default=0,
                     help="row bands whose exchange overlaps the search of the rows below them; 0 = 1 on one GPU, 4 on several")
     ap.add_argument("--dist-single", action="store_true",
@@ -111,26 +136,34 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(left: np.ndarray, right: np.ndarray, dmax: int, rows: int):
-    """Time the CPU restatement of the reference path (oracle/) on a bounded sample: the top
-    `rows` rows of the same pair, full width, full disparity range, with the reference's own
-    threading (<= 8 threads in the cost stage, serial integral images, row-parallel box sums)."""
+def cpu_baseline(left: np.ndarray, right: np.ndarray, dmax: int, rows: int, all_cores: bool):
+    """Time the CPU restatement of the reference path (oracle/) on the same pair: every row (rows = 0) or the
+    top `rows` rows, full width, full disparity range.  all_cores False: the reference's own threading (<= 8
+    threads in the cost stage, serial integral images, row-parallel box sums, one layer at a time) -- the
+    figure labelled "reference CPU path".  all_cores True: the same arithmetic with the layers dealt to every
+    core this process may use."""
     from oracle import oracle as orc
 
     orc.build()
-    rows = min(rows, left.shape[0])
+    rows = left.shape[0] if rows <= 0 else min(rows, left.shape[0])
     l, r = np.ascontiguousarray(left[:rows]), np.ascontiguousarray(right[:rows])
-    threads = min(8, os.cpu_count() or 1)
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(orc.max_threads(), allowed) if all_cores else min(8, allowed)
     t0 = time.perf_counter()
-    orc.compute_disparity(l, r, dmax, wct_radius=4, radius=3, eps_or_sigma=0.0154, threads=threads)
+    if all_cores:
+        orc.compute_disparity_allcores(l, r, dmax, wct_radius=4, radius=3, eps=0.0154, threads=threads)
+    else:
+        orc.compute_disparity(l, r, dmax, wct_radius=4, radius=3, eps_or_sigma=0.0154, threads=threads)
     dt = time.perf_counter() - t0
     evals = rows * left.shape[1] * dmax
+    what = "whole frame" if rows == left.shape[0] else f"top {rows} of {left.shape[0]} rows"
     return {
         "value": round(evals / dt / 1e6, 3),
         "unit": "MDE/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"top {rows} of {left.shape[0]} rows, full width {left.shape[1]}, dmax={dmax} "
+        "threading": "layers dealt to every core" if all_cores else "reference's (<= 8 threads in the cost stage, one layer at a time)",
+        "sample": f"{what}, full width {left.shape[1]}, dmax={dmax} "
                   f"({evals / 1e6:.1f} M evals in {dt:.1f} s; host: {host_cpu_model()}, {os.cpu_count()} CPUs)",
     }
 
@@ -162,6 +195,10 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
     lib = _native.lib()
     _native.check(lib.stereo_hip_init(local_rank))
+    library_version = lib.stereo_hip_version().decode()
+    two_call = args.path == "two-call"
+    if two_call and (world > 1 or args.dist_single or args.filter != "guided" or args.workload == "8k"):
+        raise SystemExit("--path two-call: one GPU, guided filter, motorcycle or 4k workload")
     use_dist = world > 1 or args.dist_single
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -198,7 +235,28 @@ def main() -> None:
         _native.check(lib.stereo_unpack_keys_dev(keys.data_ptr(), count, disp_out.data_ptr() + first * 4,
                                                  cost_out.data_ptr() + first * 4, stream))
 
-    if use_dist or n_bands > 1:
+    sharded = None
+    dsi = None
+    if two_call:
+        # the reference's two-call data flow on device buffers: the cost volume goes to HBM and comes back
+        dsi = torch.empty(n * D, dtype=torch.float32, device=dev)
+        frame_keys = torch.empty(n, dtype=torch.int64, device=dev)
+
+        def cost_volume() -> None:
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _native.check(lib.stereo_wct_cost_volume_dev(left.data_ptr(), right.data_ptr(), H, W, D, r_c, 8.0,
+                                                         workspace.data_ptr(), ws_bytes.value, dsi.data_ptr(), stream))
+
+        def aggregate() -> None:
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _native.check(lib.stereo_aggregate_wta_dev(dsi.data_ptr(), left.data_ptr(), H, W, D, params, 0, D,
+                                                       workspace.data_ptr(), ws_bytes.value, frame_keys.data_ptr(), stream))
+
+        def step() -> None:
+            cost_volume()
+            aggregate()
+            unpack(frame_keys, n, 0)
+    elif use_dist or n_bands > 1:
         # The kernel reports finished row bands; a side stream ships each band as soon as it is final: every rank
         # sends pixel slice j of the band's keys to rank j over its direct xGMI link, min-merges the N slices it
         # receives and hands its merged slice to rank 0, while the kernel searches the bands below.
@@ -225,7 +283,7 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     fence()
-    _native.check(lib.stereo_profile_begin(args.steps))
+    _native.check(lib.stereo_profile_begin(0 if two_call else args.steps))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -234,6 +292,28 @@ def main() -> None:
     kernel_ms, launches = ctypes.c_double(0.0), ctypes.c_int(0)
     _native.check(lib.stereo_profile_end(ctypes.byref(kernel_ms), ctypes.byref(launches)))
     kernel_step_ms = kernel_ms.value / max(launches.value, 1)
+    two_call_info = None
+    if two_call:
+        # each of the two kernels on its own, events on the launch stream
+        timed = {}
+        for name, fn in (("dsi_kernel", cost_volume), ("fused_guided_kernel<SRC_DSI>", aggregate)):
+            fn()
+            torch.cuda.synchronize()
+            _native.check(lib.stereo_profile_begin(args.steps))
+            for _ in range(args.steps):
+                fn()
+            torch.cuda.synchronize()
+            _native.check(lib.stereo_profile_end(ctypes.byref(kernel_ms), ctypes.byref(launches)))
+            timed[name] = kernel_ms.value / max(launches.value, 1)
+        kernel_step_ms = timed["fused_guided_kernel<SRC_DSI>"]
+        vol_bytes = n * D * 4
+        two_call_info = {
+            "cost_volume_bytes": vol_bytes,
+            "dsi_kernel_ms": round(timed["dsi_kernel"], 4),
+            "dsi_kernel_write_gbs": round(vol_bytes / (timed["dsi_kernel"] * 1e-3) / 1e9, 1),
+            "aggregate_kernel_ms": round(kernel_step_ms, 4),
+            "aggregate_kernel_read_gbs": round(vol_bytes / (kernel_step_ms * 1e-3) / 1e9, 1),
+        }
     if use_dist:
         t = torch.tensor([elapsed, kernel_step_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -243,7 +323,8 @@ def main() -> None:
 
     # untimed self-check of the sharded / banded result against one unsharded whole-frame search on rank 0
     merge_check = None
-    if use_dist or n_bands > 1:
+    error = None
+    if sharded is not None:
         # one more (untimed) step on poisoned buffers, so that data left over from earlier steps cannot pass
         for t in [exchange.keys, disp, cost] + [b.recv for b in exchange.bands if b.recv is not None] + \
                  [b.frame for b in exchange.bands if b.frame is not None]:
@@ -251,7 +332,8 @@ def main() -> None:
         fence()
         step()
         fence()
-    if rank == 0 and (use_dist or n_bands > 1):
+    differ = 0
+    if rank == 0 and sharded is not None:
         ref_keys = torch.empty(n, dtype=torch.int64, device=dev)
         ref_disp, ref_cost = torch.empty_like(disp), torch.empty_like(cost)
         search(0, D, 0, H, ref_keys)
@@ -261,6 +343,14 @@ def main() -> None:
         rel = float(((ref_cost - cost).abs() / ref_cost.abs().clamp_min(1.0)).max().item())
         merge_check = {"pixels_differing_from_unsharded": differ, "max_rel_cost_diff": rel, "pixels": n,
                        "band_waits_timed_out": int((progress[32:48] != 0).sum().item())}
+    if sharded is not None:
+        # collective checks: every rank learns of a failure on any rank, so all of them end the same way
+        try:
+            sharded.check()
+            sharding.raise_if_any_rank_failed(differ, "pixels of the sharded frame differ from the unsharded search",
+                                              use_dist, dev)
+        except RuntimeError as exc:
+            error = str(exc)
 
     copy_gbs = None
     if rank == 0:
@@ -281,11 +371,26 @@ def main() -> None:
         evals = H * W * D
         ms_per_step = elapsed / args.steps * 1e3
         d_local = d_end - d_begin
-        alg_bytes = H * W * (8 * d_local + 16)  # DSI-equivalent bytes of one fused launch
+        # fused: DSI-equivalent bytes of one launch (8 B per eval + 16 B per pixel); two-call: the bytes the
+        # aggregation kernel really reads (the float32 volume) and writes (one key per pixel)
+        alg_bytes = H * W * (4 * D + 8 + 4) if two_call else H * W * (8 * d_local + 16)
         achieved = alg_bytes / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+        traffic = measured_hbm_traffic(args.workload, library_version) if world == 1 and args.filter == "guided" and not two_call else None
+        lds_rate, valu_busy = counter_ratios(args.workload, library_version) if traffic is not None else (None, None)
+        if two_call:
+            kernel_name = "fused_guided_kernel<SRC_DSI>"
+            note = ("two-call path: the float32 cost volume is written by dsi_kernel and read back by the aggregation "
+                    "kernel, so the bytes are real HBM bytes (4 B per pixel-disparity read + 12 B per pixel); see two_call")
+        else:
+            kernel_name = DOMINANT_KERNEL if args.filter == "guided" else "fused_filter_kernel"
+            note = ("DSI-equivalent % of HBM peak: 8 B per pixel-disparity (a float32 cost volume written once "
+                    "and read once, which the fused kernel never materialises) + 16 B per pixel; traffic = "
+                    "measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate run of this "
+                    "command on this build of the library, null when no such run is committed); the kernel is "
+                    "bound by vector-instruction issue (lane-shift and float64 ops), not by HBM")
         out = {
-            "metric": f"MDE/s (10^6 pixel-disparity evals/s), fused WCT+{args.filter}+WTA",
-            "value": round(evals * args.steps / elapsed / 1e6, 1),
+            "metric": f"MDE/s (10^6 pixel-disparity evals/s), {'two-call' if two_call else 'fused'} WCT+{args.filter}+WTA",
+            "value": None if error else round(evals * args.steps / elapsed / 1e6, 1),
             "unit": "MDE/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -302,25 +407,30 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_hbm_traffic(args.workload) if world == 1 and args.filter == "guided" else None,
-                "kernel": DOMINANT_KERNEL if args.filter == "guided" else "fused_filter_kernel", "kernel_ms": round(kernel_avg_ms, 4),
+                "traffic": traffic,
+                "kernel": kernel_name, "kernel_ms": round(kernel_avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "compulsory_frac": round(H * W * 16 / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 if kernel_avg_ms > 0 else None,
                 "measured_copy_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
-                "lds_bank_conflict_rate": counter_ratios(args.workload)[0] if world == 1 and args.filter == "guided" else None,
-                "valu_busy": counter_ratios(args.workload)[1] if world == 1 and args.filter == "guided" else None,
-                "note": "DSI-equivalent % of HBM peak: 8 B per pixel-disparity (a float32 cost volume written once "
-                        "and read once, which the fused kernel never materialises) + 16 B per pixel; traffic = "
-                        "measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate run of this "
-                        "command); the kernel is bound by vector-instruction issue (lane-shift and float64 ops), "
-                        "not by HBM",
+                "lds_bank_conflict_rate": lds_rate,
+                "valu_busy": valu_busy,
+                "library": library_version,
+                "note": note,
             },
         }
+        if error:
+            out["error"] = error
+        if two_call_info is not None:
+            out["two_call"] = two_call_info
         if merge_check is not None:
             out["merge_check"] = merge_check
-        if world == 1 and not args.no_cpu_baseline and args.filter == "guided" and r_c == 4:
-            out["cpu_baseline"] = cpu_baseline(left_np, right_np, D, args.cpu_rows)
+        if world == 1 and not args.no_cpu_baseline and args.filter == "guided" and r_c == 4 and not error:
+            del dsi
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(left_np, right_np, D, args.cpu_rows, all_cores=False)
+            if not args.no_cpu_all_cores:
+                out["cpu_baseline_all_cores"] = cpu_baseline(left_np, right_np, D, args.cpu_rows, all_cores=True)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
@@ -328,6 +438,10 @@ def main() -> None:
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if error:
+        # (every rank holds the same verdict: the checks above are collective)
+        print(f"[bench] rank {rank}: FAILED: {error}", file=sys.stderr, flush=True)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

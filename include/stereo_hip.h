@@ -139,6 +139,17 @@ int stereo_fused_workspace_bytes(int height, int width, const StereoParams *para
 int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int height, int width, int dmax,
                                  const StereoParams *params, int d_begin, int d_end, void *d_workspace,
                                  size_t workspace_bytes, uint64_t *d_keys, void *stream);
+/* The two-call form of the path on device buffers, the data flow the reference's public API defines:
+ * census.compute_wct_cost_volume (census.py:205-269) writes d_dsi[H][W][dmax] float32 (D innermost, census.py:250)
+ * from float32 device images, and stereo.aggregate_and_wta (stereo.py:94-174, guided filter, radius 1..4,
+ * float32 guide, finite costs) reads it back layer by layer (stereo.py:146) and writes one packed key per pixel.
+ * d_workspace / workspace_bytes as for stereo_compute_disparity_dev (params->wct_radius sizes it). */
+int stereo_wct_cost_volume_dev(const float *d_left, const float *d_right, int height, int width, int dmax, int radius,
+                               double base_weight, void *d_workspace, size_t workspace_bytes, float *d_dsi,
+                               void *stream);
+int stereo_aggregate_wta_dev(const float *d_dsi, const float *d_guide, int height, int width, int dmax,
+                             const StereoParams *params, int d_begin, int d_end, void *d_workspace,
+                             size_t workspace_bytes, uint64_t *d_keys, void *stream);
 /* keys[i] = min(keys[i], other[i]) -- local merge of two disparity shards. */
 int stereo_merge_keys_dev(uint64_t *d_keys, const uint64_t *d_other, size_t n, void *stream);
 /* The same over n_slices equal-length slices laid end to end (what an all-to-all of key slices
@@ -180,6 +191,9 @@ int stereo_wait_progress_dev(const uint32_t *d_progress, int band, uint32_t epoc
  * no counterpart in the reference.  This returns every cached buffer to the driver. */
 int stereo_hip_release_cache(void);
 
+/* The test hook and the profile below, like the buffer cache above, are process-global state: ONE caller at a
+ * time per process (the reference's own contract: one synchronous call per scene from one thread,
+ * stereo.py:665-681).  None of them is thread-safe. */
 /* Test hook, no counterpart in the reference: selects the fused guided kernel compute_disparity
  * uses, so the variants can be compared on the same input.  0 = the best one that applies
  * (default), 1 = the general kernel (float64 sums exchanged through LDS), 2 = the fast kernel

@@ -208,6 +208,23 @@ def compute_disparity(left: np.ndarray, right: np.ndarray, dmax: int, wct_radius
     return disp, cost
 
 
+def compute_disparity_allcores(left: np.ndarray, right: np.ndarray, dmax: int, wct_radius: int = 4,
+                               base_weight: float = 8.0, radius: int = 3, eps: float = 0.0154, threads: int = 0):
+    """compute_disparity (guided filter) with the layers dealt to `threads` workers (0 = all the runtime offers):
+    same arithmetic per layer, bit-identical result, not the reference's threading."""
+    l = np.ascontiguousarray(left, dtype=np.float32)
+    r = np.ascontiguousarray(right, dtype=np.float32)
+    h, w = l.shape
+    disp = np.empty((h, w), dtype=np.int32)
+    cost = np.empty((h, w), dtype=np.float32)
+    rc = lib().orc_compute_disparity_allcores(_ptr(l), _ptr(r), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(dmax),
+                                              ctypes.c_int(wct_radius), ctypes.c_double(base_weight), ctypes.c_int(radius),
+                                              ctypes.c_double(eps), _ptr(disp), _ptr(cost),
+                                              ctypes.c_int(threads or max_threads()))
+    _check(rc, "compute_disparity_allcores")
+    return disp, cost
+
+
 # ---- steps either side of the hot path (numpy restatements; test infrastructure only) ----------
 def to_gray(image: np.ndarray, normalize: bool = False, max_value=None) -> np.ndarray:
     """Reference stereo_io.py:47-75 with stereo_io.py:22-44 for the scale: float32 products and

@@ -569,6 +569,81 @@ int orc_compute_disparity(const float *left, const float *right, int height, int
     return rc;
 }
 
+/* The same computation with every core busy (NOT the reference's threading, which keeps at most
+ * parallel_chunk = 8 threads in the cost stage and filters one layer at a time, stereo.py:145-172):
+ * the cost stage runs `threads` disparities at once and the layers are dealt round-robin to `threads`
+ * workers, each with private buffers and a private WTA over its layers in increasing d; the workers'
+ * results are merged by (cost, d) -- strict '<', ties to the lower disparity.  Every layer goes through
+ * the same arithmetic as in orc_aggregate_and_wta, so the result is bit-identical; only the schedule
+ * differs.  Timed by bench.py as the all-cores CPU figure.  Guided filter only. */
+int orc_compute_disparity_allcores(const float *left, const float *right, int height, int width, int dmax,
+                                   int wct_radius, double base_weight, int radius, double eps,
+                                   int32_t *disparity, float *min_cost, int threads) {
+    size_t n = (size_t)height * width;
+    if (threads < 1) threads = 1;
+    if (threads > dmax) threads = dmax;
+    float *dsi = (float *)malloc(sizeof(float) * n * (size_t)dmax);
+    double *guide = (double *)malloc(sizeof(double) * n);
+    double *mean_guide = (double *)malloc(sizeof(double) * n), *var_g = (double *)malloc(sizeof(double) * n);
+    float *best_c = (float *)malloc(sizeof(float) * n * (size_t)threads);
+    int32_t *best_d = (int32_t *)malloc(sizeof(int32_t) * n * (size_t)threads);
+    int rc = (dsi && guide && mean_guide && var_g && best_c && best_d) ? ORC_OK : ORC_ENOMEM;
+    if (rc == ORC_OK) {
+        for (size_t i = 0; i < n; ++i) guide[i] = (double)left[i];
+        rc = orc_wct_cost_volume(left, right, ORC_F32, height, width, dmax, wct_radius, base_weight, dsi, threads,
+                                 threads);
+    }
+    if (rc == ORC_OK) rc = orc_guided_prepare(guide, height, width, radius, mean_guide, var_g, threads);
+    if (rc == ORC_OK) {
+        int failed = 0;
+        #pragma omp parallel num_threads(threads)
+        {
+#ifdef _OPENMP
+            const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+            const int tid = 0, nt = 1;
+#endif
+            float *layer = (float *)malloc(sizeof(float) * n), *filtered = (float *)malloc(sizeof(float) * n);
+            float *mc = best_c + (size_t)tid * n;
+            int32_t *md = best_d + (size_t)tid * n;
+            for (size_t i = 0; i < n; ++i) { mc[i] = INFINITY; md[i] = 0; }
+            if (!layer || !filtered) {
+                #pragma omp atomic write
+                failed = 1;
+            } else {
+                for (int d = tid; d < dmax; d += nt) {
+                    for (size_t i = 0; i < n; ++i) layer[i] = dsi[i * dmax + d];
+                    if (orc_guided_apply(guide, mean_guide, var_g, layer, height, width, radius, eps, filtered, 1) != ORC_OK) {
+                        #pragma omp atomic write
+                        failed = 1;
+                        break;
+                    }
+                    orc_wta_update(filtered, n, d, mc, md);
+                }
+            }
+            free(layer); free(filtered);
+            /* workers beyond the team size the runtime granted hold nothing */
+            #pragma omp single
+            for (int t = nt; t < threads; ++t)
+                for (size_t i = 0; i < n; ++i) { best_c[(size_t)t * n + i] = INFINITY; best_d[(size_t)t * n + i] = 0; }
+        }
+        if (failed) rc = ORC_ENOMEM;
+    }
+    if (rc == ORC_OK)
+        for (size_t i = 0; i < n; ++i) {
+            float c = INFINITY;
+            int32_t d = 0;
+            for (int t = 0; t < threads; ++t) {
+                const float ct = best_c[(size_t)t * n + i];
+                const int32_t dt = best_d[(size_t)t * n + i];
+                if (ct < c || (ct == c && ct < INFINITY && dt < d)) { c = ct; d = dt; }
+            }
+            min_cost[i] = c; disparity[i] = d;
+        }
+    free(dsi); free(guide); free(mean_guide); free(var_g); free(best_c); free(best_d);
+    return rc;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -6,6 +6,13 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OUT="$HERE/libstereo_hip.so"
 SRCS=("$HERE"/csrc/*.hip)
 mkdir -p "$HERE/csrc/obj"
+# Build id = hash of every source that goes into the library; stereo_hip_version() reports it, so that a counter
+# summary under profiles/ can be matched with the library it was taken on.
+BUILD_ID="$(cat "$HERE"/csrc/*.hip "$HERE"/csrc/*.hpp "$HERE/../include/stereo_hip.h" | sha256sum | cut -c1-12)"
+if [[ "$(cat "$HERE/csrc/obj/build_id.txt" 2>/dev/null)" != "$BUILD_ID" ]]; then
+  rm -f "$HERE/csrc/obj/api.o"
+  echo "$BUILD_ID" > "$HERE/csrc/obj/build_id.txt"
+fi
 OBJS=()
 pids=()
 for src in "${SRCS[@]}"; do
@@ -15,7 +22,10 @@ for src in "${SRCS[@]}"; do
     # The fused kernels keep two independent columns per lane in scalar registers: packing them into
     # v_pk_* instructions costs register shuffles and issues no faster on gfx950.
     file_flags=""
-    case "$(basename "$src")" in guided_pair.hip|guided_fast.hip) file_flags="-fno-slp-vectorize" ;; esac
+    case "$(basename "$src")" in
+      guided_pair.hip|guided_fast.hip) file_flags="-fno-slp-vectorize" ;;
+      api.hip) file_flags="-DSTEREO_BUILD_ID=\"$BUILD_ID\"" ;;
+    esac
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$HERE/../include" -I"$HERE/csrc" \
       -Wall -Wno-unused-function $file_flags ${EXTRA_HIPCC_FLAGS:-} -c "$src" -o "$obj" &
     pids+=($!)

@@ -388,7 +388,10 @@ using namespace shp;
 extern "C" {
 
 const char *stereo_hip_last_error(void) { return g_err; }
-const char *stereo_hip_version(void) { return "stereo_hip 0.1 (gfx950)"; }
+#ifndef STEREO_BUILD_ID
+#define STEREO_BUILD_ID "unknown"
+#endif
+const char *stereo_hip_version(void) { return "stereo_hip 0.2 (gfx950) build " STEREO_BUILD_ID; }
 
 int stereo_hip_device_count(int *count) {
     if (!count) { set_error("null pointer"); return STEREO_EINVAL; }
@@ -475,6 +478,66 @@ int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int 
     if (!d_left || !d_right || !p || !ws || !d_keys) { set_error("null pointer"); return STEREO_EINVAL; }
     return fused_disparity_dev(d_left, d_right, H, W, dmax, p, d_begin, d_end, ws, ws_bytes, d_keys, nullptr,
                                static_cast<hipStream_t>(stream));
+}
+
+// Event pair of the profile around one kernel (or kernel chain) of a device entry point.
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    explicit ProfScope(hipStream_t stream) : s(stream), on(g_prof.enabled && g_prof.used < (int)g_prof.start.size()) {}
+    int begin() { return on ? (hipEventRecord(g_prof.start[g_prof.used], s) == hipSuccess ? STEREO_OK : STEREO_EHIP) : STEREO_OK; }
+    int end() {
+        if (!on) return STEREO_OK;
+        if (hipEventRecord(g_prof.stop[g_prof.used], s) != hipSuccess) return STEREO_EHIP;
+        ++g_prof.used;
+        return STEREO_OK;
+    }
+};
+
+int stereo_wct_cost_volume_dev(const float *d_left, const float *d_right, int H, int W, int dmax, int radius,
+                               double base_weight, void *ws, size_t ws_bytes, float *d_dsi, void *stream) {
+    if (!d_left || !d_right || !ws || !d_dsi) { set_error("null pointer"); return STEREO_EINVAL; }
+    if (dmax <= 0) { set_error("dmax must be a positive integer"); return STEREO_EINVAL; }
+    SHP_TRY(check_image_dims(H, W));
+    CensusCfg cfg;
+    SHP_TRY(make_census_cfg(radius, base_weight, &cfg));
+    FusedWs L = fused_ws_layout(H, W, radius);
+    if (ws_bytes < L.total) { set_error("workspace too small: %zu < %zu", ws_bytes, L.total); return STEREO_EINVAL; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned char *base = static_cast<unsigned char *>(ws);
+    void *lw = base + L.off_lw, *rw = base + L.off_rw;
+    SHP_TRY(launch_census_pack_pair(d_left, d_right, STEREO_DT_F32, H, W, radius, lw, rw, s));
+    ProfScope prof(s);
+    SHP_TRY(prof.begin());
+    SHP_TRY(launch_dsi(lw, rw, H, W, dmax, cfg, d_dsi, s));
+    return prof.end();
+}
+
+int stereo_aggregate_wta_dev(const float *d_dsi, const float *d_guide, int H, int W, int dmax, const StereoParams *p,
+                             int d_begin, int d_end, void *ws, size_t ws_bytes, uint64_t *d_keys, void *stream) {
+    if (!d_dsi || !d_guide || !p || !ws || !d_keys) { set_error("null pointer"); return STEREO_EINVAL; }
+    SHP_TRY(check_params(p));
+    SHP_TRY(check_image_dims(H, W));
+    if (dmax <= 0) { set_error("dsi must have at least one disparity layer"); return STEREO_EINVAL; }
+    if (d_begin < 0 || d_end > dmax || d_begin > d_end) { set_error("bad disparity range"); return STEREO_EINVAL; }
+    if (p->filter_kind != STEREO_FILTER_GUIDED || !fused_guided_supported(p->guided_radius)) {
+        set_error("the device entry point aggregates with the guided filter, radius 1..4");
+        return STEREO_EUNSUPPORTED;
+    }
+    FusedWs L = fused_ws_layout(H, W, p->wct_radius);
+    if (ws_bytes < L.total) { set_error("workspace too small: %zu < %zu", ws_bytes, L.total); return STEREO_EINVAL; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned char *base = static_cast<unsigned char *>(ws);
+    double *mean = reinterpret_cast<double *>(base + L.off_mean);
+    double *invden = reinterpret_cast<double *>(base + L.off_invden);
+    SHP_TRY(launch_guide_stats(d_guide, STEREO_DT_F32, H, W, p->guided_radius, p->guided_eps, mean, invden,
+                               base + L.off_gmax, s));
+    if (d_begin == d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
+    ProfScope prof(s);
+    SHP_TRY(prof.begin());
+    SHP_TRY(launch_fused_guided(nullptr, nullptr, nullptr, d_dsi, d_guide, STEREO_DT_F32, mean, invden, H, W, dmax,
+                                p->guided_radius, d_begin, d_end, d_keys, nullptr, 0, s));
+    return prof.end();
 }
 
 int stereo_progress_plan(int H, int W, const StereoParams *p, int n_bands, int32_t *row_end, int *bands_out) {
@@ -597,6 +660,8 @@ int stereo_unpack_keys_dev(const uint64_t *d_keys, size_t n, int32_t *d_disp, fl
 // kernels, one for waits, unpacking and copies; created at first use (one caller at a time per device).
 struct HostOverlap {
     hipStream_t compute = nullptr, copy = nullptr;
+    hipEvent_t words_cleared = nullptr;   // orders the copy stream's first wait behind the clearing of the progress words
+    uint32_t epoch = 0;                   // one per call: a recycled words buffer never holds a flag of the current call
 };
 static HostOverlap *host_overlap_for_current_device() {
     static HostOverlap table[64];
@@ -607,9 +672,14 @@ static HostOverlap *host_overlap_for_current_device() {
     HostOverlap &h = table[dev];
     if (!h.compute) {
         hipStream_t a = nullptr, b = nullptr;
+        hipEvent_t e = nullptr;
         if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(a); return nullptr; }
-        h.compute = a; h.copy = b;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(a); (void)hipStreamDestroy(b);
+            return nullptr;
+        }
+        h.compute = a; h.copy = b; h.words_cleared = e;
     }
     return &h;
 }
@@ -658,13 +728,19 @@ int stereo_compute_disparity_host(const void *left, const void *right, int dtype
             DevBuf words, disp, cost;
             SHP_TRY(words.alloc(sizeof(uint32_t) * 3 * PROGRESS_MAX_BANDS));
             SHP_TRY(disp.alloc(n * 4)); SHP_TRY(cost.alloc(n * 4));
+            // The words come from the recycled pool: they are cleared before anything polls them (the copy
+            // stream's first wait is ordered behind the clearing by an event), and the epoch differs from every
+            // earlier call's, so a flag left in the buffer can never pass for this call's.
+            const uint32_t epoch = ++ov->epoch ? ov->epoch : ++ov->epoch;
             SHP_HIP(hipMemsetAsync(words.p, 0, sizeof(uint32_t) * 3 * PROGRESS_MAX_BANDS, ov->compute));
+            SHP_HIP(hipEventRecord(ov->words_cleared, ov->compute));
+            SHP_HIP(hipStreamWaitEvent(ov->copy, ov->words_cleared, 0));
             int rc = stereo_compute_disparity_progress_dev(dl.as<float>(), dr.as<float>(), H, W, dmax, p, d_begin, d_end,
                                                            ws.p, L.total, keys.as<uint64_t>(), n_bands,
-                                                           words.as<uint32_t>(), 1u, ov->compute);
+                                                           words.as<uint32_t>(), epoch, ov->compute);
             for (int b = 0, y0 = 0; rc == STEREO_OK && b < n_bands; y0 = row_end[b], ++b) {
                 const size_t first = (size_t)y0 * W, count = (size_t)(row_end[b] - y0) * W;
-                rc = launch_progress_wait(words.as<uint32_t>(), b, 1u, ov->copy);
+                rc = launch_progress_wait(words.as<uint32_t>(), b, epoch, ov->copy);
                 if (rc == STEREO_OK)
                     rc = launch_unpack_keys(keys.as<uint64_t>() + first, count, disp.as<int32_t>() + first,
                                             cost.as<float>() + first, ov->copy);
@@ -680,6 +756,15 @@ int stereo_compute_disparity_host(const void *left, const void *right, int dtype
             const hipError_t e1 = hipStreamSynchronize(ov->copy), e2 = hipStreamSynchronize(ov->compute);
             SHP_TRY(rc);
             SHP_HIP(e1); SHP_HIP(e2);
+            // a band wait that gave up shipped rows that were not final: that is an error, not a result
+            uint32_t timed_out[PROGRESS_MAX_BANDS];
+            SHP_HIP(hipMemcpy(timed_out, words.as<uint32_t>() + 2 * PROGRESS_MAX_BANDS, sizeof(timed_out),
+                              hipMemcpyDeviceToHost));
+            for (int b = 0; b < n_bands; ++b)
+                if (timed_out[b] != 0) {
+                    set_error("the wait for row band %d of %d timed out: the rows copied out were not final", b, n_bands);
+                    return STEREO_EHIP;
+                }
         } else {
             SHP_TRY(fused_disparity_dev(dl.as<float>(), dr.as<float>(), H, W, dmax, p, d_begin, d_end, ws.p, L.total,
                                         keys.as<uint64_t>(), nullptr, nullptr));

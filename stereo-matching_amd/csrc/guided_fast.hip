@@ -407,14 +407,6 @@ static int launch_fast_q(const FastArgs &a, hipStream_t s) {
 }
 template <int RG, bool WORD64>
 static int launch_fast_t(const FastArgs &a, hipStream_t s) {
-#ifdef FF_EXPERIMENT_NW
-    if (RG == 3 && !WORD64 && !a.q_out) {
-        const char *e = getenv("STEREO_FAST_NW");
-        int nw = e ? atoi(e) : 16;
-        if (nw == 8) return launch_fast_q<3, false, false, 8>(a, s);
-        if (nw == 12) return launch_fast_q<3, false, false, 12>(a, s);
-    }
-#endif
     return a.q_out ? launch_fast_q<RG, WORD64, true>(a, s) : launch_fast_q<RG, WORD64, false>(a, s);
 }
 

@@ -3,6 +3,9 @@
 //
 // words[0 .. 15]   finished workgroups per band (the kernel counts, the launcher clears)
 // words[16 .. 31]  band flags: the launch's epoch once the band's keys are final
+// words[32 .. 47]  time-out marks: non-zero once a wait for the band gave up (never cleared by the library:
+//                  the caller clears them with the rest when it allocates the words, and must treat a
+//                  non-zero mark as a failed frame)
 //
 // The flags are set by the fused kernel where it supports it and, in every case, by
 // progress_finish_kernel enqueued right after it, so a waiter never depends on which kernel ran.
@@ -27,7 +30,8 @@ __global__ __launch_bounds__(64) void progress_wait_kernel(uint32_t *words, int 
                                                 __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int32_t)(seen - epoch) >= 0) break;
         if (wall_clock64() - t0 > 1000000000ull) {
-            words[2 * PROGRESS_MAX_BANDS + band] = epoch;
+            __hip_atomic_store(&words[2 * PROGRESS_MAX_BANDS + band], epoch ? epoch : 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
         __builtin_amdgcn_s_sleep(64);

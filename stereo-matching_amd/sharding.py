@@ -80,6 +80,25 @@ def gather_slices(part, world: int, rank: int, dst: int = 0, out=None):
     return out
 
 
+def raise_if_any_rank_failed(local_failures: int, what: str, use_dist: bool, device="cpu") -> None:
+    """Collective error check: every rank passes the number of failures IT saw (timed-out band waits, pixels that
+    differ from a reference, ...).  One small all_reduce makes the counts known everywhere, and RuntimeError is
+    raised on EVERY rank when any rank counted one -- a rank that raised alone would leave its peers blocked in the
+    next collective.  Without a process group (`use_dist` false) only the local count is looked at."""
+    import torch
+    import torch.distributed as dist
+
+    counts = [int(local_failures)]
+    if use_dist and dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(), dist.get_rank()
+        t = torch.zeros(world, dtype=torch.int64, device=device)
+        t[rank] = int(local_failures)
+        dist.all_reduce(t)
+        counts = [int(v) for v in t.tolist()]
+    if any(counts):
+        raise RuntimeError(f"{what}: failures per rank {counts}")
+
+
 class _Band:
     __slots__ = ("y0", "y1", "n", "chunk", "send", "recv", "frame")
 
@@ -207,6 +226,10 @@ class ShardedFrameSearch:
         self.progress = torch.zeros(48, dtype=torch.int32, device=self.device)
         self.exchange = OverlappedExchange(height, width, world, rank, list(row_end[:self.n_bands]), self.device,
                                            use_dist=self.use_dist)
+        if self.exchange.side is not None:
+            # the first band wait polls the progress words on the side stream: it must not run ahead of the
+            # kernel that clears them above
+            self.exchange.side.wait_stream(torch.cuda.current_stream(self.device))
         n = height * width
         self.disparity = torch.zeros(n, dtype=torch.int32, device=self.device) if rank == 0 else None
         self.min_cost = torch.full((n,), float("inf"), dtype=torch.float32, device=self.device) if rank == 0 else None
@@ -251,6 +274,14 @@ class ShardedFrameSearch:
     def band_waits_timed_out(self) -> int:
         """Band waits that gave up (a producer that never ran); 0 in a healthy run.  Synchronises."""
         return int((self.progress[32:48] != 0).sum().item())
+
+    def check(self) -> None:
+        """Collective: raises RuntimeError on every rank if a band wait timed out on any rank since this object
+        was made.  A timed-out wait lets keys travel that were not final, so every frame produced since then is
+        suspect; call this after synchronising and before using the results.  Synchronises."""
+        raise_if_any_rank_failed(self.band_waits_timed_out(),
+                                 "row-band waits of the sharded search timed out (the rows shipped were not final)",
+                                 self.use_dist, self.device)
 
 
 def deal_scenes(sizes: Sequence[int], world: int) -> List[List[int]]:

@@ -267,8 +267,7 @@ def compute_disparity_sharded(
     right_dev = torch.from_numpy(right32).to(device).view(-1)
     disparity, min_cost = search.run(left_dev, right_dev)
     torch.cuda.synchronize(device)
-    if search.band_waits_timed_out():
-        raise RuntimeError("a row band was never reported finished: the search kernel did not run")
+    search.check()   # collective: a timed-out band wait on any rank raises on every rank
     if rank != 0:
         return None, None
     return disparity.view(height, width).cpu().numpy(), min_cost.view(height, width).cpu().numpy()

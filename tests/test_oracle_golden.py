@@ -180,3 +180,24 @@ def test_roll_known_answer(oracle):
     assert np.bincount(disp[8:24, 16:36].ravel()).argmax() == k
     const = np.full((32, 48), 1200.0, dtype=np.float32)
     assert np.all(oracle.guided_filter(left, const, 3, 0.0154) == 1200.0)
+
+
+def test_all_cores_schedule_is_bit_identical():
+    """The all-cores schedule bench.py times as its second CPU figure deals the layers to workers and merges
+    their (cost, d) minima; per layer it runs the same arithmetic, so the frame must equal the reference
+    schedule's bit for bit (ties included: the synthetic pair has wide constant `large` regions)."""
+    import sys
+
+    from conftest import PKG_DIR
+    if PKG_DIR not in sys.path:
+        sys.path.insert(0, PKG_DIR)
+    from oracle import oracle as orc
+    from synth import synth_pair_gray
+
+    orc.build()
+    left, right, _ = synth_pair_gray(61, 97, 29, seed=11)
+    d_ref, c_ref = orc.compute_disparity(left, right, 29, threads=3)
+    for threads in (1, 4, 7):
+        d_all, c_all = orc.compute_disparity_allcores(left, right, 29, threads=threads)
+        assert np.array_equal(d_all, d_ref)
+        assert np.array_equal(c_all.view(np.uint32), c_ref.view(np.uint32))

@@ -96,6 +96,17 @@ def _worker(rank: int, world: int, port: int, out_path: str) -> None:
 
         for _ in range(2):  # twice: buffers are reused from step to step
             ox.run(search, lambda band, epoch: waited.append((band, epoch)), merge_slices, unpack)
+        # the collective error check: nobody failed -> nobody raises; the LAST rank alone reports a timed-out band
+        # wait -> every rank raises, with the per-rank counts in the message
+        sharding.raise_if_any_rank_failed(0, "band waits", True)
+        try:
+            sharding.raise_if_any_rank_failed(1 if rank == world - 1 else 0, "band waits", True)
+            raised = False
+        except RuntimeError as exc:
+            expected = [0] * (world - 1) + [1]
+            raised = str(expected) in str(exc)
+        with open(f"{out_path}.raised{rank}", "w") as f:
+            f.write("raised" if raised else "silent")
         if rank == 0:
             ok = ok and np.array_equal(out_d.reshape(h, w), dref) and np.array_equal(out_c.reshape(h, w), cref)
             ok = ok and waited == [(0, 1), (1, 1), (2, 1), (0, 2), (1, 2), (2, 2)]
@@ -121,6 +132,8 @@ def test_disparity_shards_merge_over_gloo(world):
         out = os.path.join(tmp, "result.txt")
         mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
         assert open(out).read() == "ok"
+        # an injected timed-out band wait on one rank raised on all of them
+        assert [open(f"{out}.raised{r}").read() for r in range(world)] == ["raised"] * world
 
 
 def test_key_roundtrip_and_order():

@@ -18,5 +18,6 @@ run sq2 SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_
 run grbm GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-python3 "$ROOT/tools/pmc_summary.py" "$OUT/sq1" "$OUT/sq2" "$OUT/grbm" "$OUT/fetch" "$OUT/write" > "$OUT/pmc_per_launch.json"
+VERSION="$(cd "$ROOT" && python3 -c 'import sys; sys.path.insert(0, "stereo-matching_amd"); import _native; print(_native.lib().stereo_hip_version().decode())')"
+python3 "$ROOT/tools/pmc_summary.py" --library-version "$VERSION" "$OUT/sq1" "$OUT/sq2" "$OUT/grbm" "$OUT/fetch" "$OUT/write" > "$OUT/pmc_per_launch.json"
 echo "summary in $OUT/pmc_per_launch.json"
