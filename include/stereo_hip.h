@@ -150,6 +150,18 @@ int stereo_wct_cost_volume_dev(const float *d_left, const float *d_right, int he
 int stereo_aggregate_wta_dev(const float *d_dsi, const float *d_guide, int height, int width, int dmax,
                              const StereoParams *params, int d_begin, int d_end, void *d_workspace,
                              size_t workspace_bytes, uint64_t *d_keys, void *stream);
+/* stereo_compute_disparity_dev without the workspace argument.  No counterpart in the reference; it is for
+ * callers that cannot allocate device memory or carry a workspace: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  The scratch (census words, guide statistics, per-layer ranges) is a
+ * static device array inside the library, about 34 MB per GPU, sized for frames of at most
+ * STEREO_NOALLOC_MAX_PIXELS pixels (any census radius); larger frames return STEREO_EINVAL.  The call allocates
+ * nothing (no hipMalloc / hipFree, no library routine that allocates) and, like the other *_dev entry points,
+ * only enqueues work on `stream`.  All calls on one GPU share that GPU's array: calls that overlap in time on one
+ * GPU (two streams, two threads) race on it -- run them one after the other. */
+#define STEREO_NOALLOC_MAX_PIXELS 1048576
+int stereo_compute_disparity_noalloc_dev(const float *d_left, const float *d_right, int height, int width, int dmax,
+                                         const StereoParams *params, int d_begin, int d_end, uint64_t *d_keys,
+                                         void *stream);
 /* keys[i] = min(keys[i], other[i]) -- local merge of two disparity shards. */
 int stereo_merge_keys_dev(uint64_t *d_keys, const uint64_t *d_other, size_t n, void *stream);
 /* The same over n_slices equal-length slices laid end to end (what an all-to-all of key slices

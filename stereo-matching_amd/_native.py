@@ -58,6 +58,7 @@ _SIGNATURES = {
     "stereo_aggregate_wta_host": [_VP, _VP, _I, _I, _I, _I, _PP, _I, _I, _VP, _VP],
     "stereo_compute_disparity_host": [_VP, _VP, _I, _I, _I, _I, _PP, _I, _I, _VP, _VP],
     "stereo_fused_workspace_bytes": [_I, _I, _PP, ctypes.POINTER(ctypes.c_size_t)],
+    "stereo_compute_disparity_noalloc_dev": [_VP, _VP, _I, _I, _I, _PP, _I, _I, _VP, _VP],
     "stereo_wct_cost_volume_dev": [_VP, _VP, _I, _I, _I, _I, _D, _VP, _SZ, _VP, _VP],
     "stereo_aggregate_wta_dev": [_VP, _VP, _I, _I, _I, _PP, _I, _I, _VP, _SZ, _VP, _VP],
     "stereo_compute_disparity_dev": [_VP, _VP, _I, _I, _I, _PP, _I, _I, _VP, _SZ, _VP, _VP],

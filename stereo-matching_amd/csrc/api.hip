@@ -385,6 +385,32 @@ static int guide_is_finite(const void *d_gmax, bool *finite) {
 
 using namespace shp;
 
+// ---- scratch of the entry point that allocates nothing --------------------------------------------------------
+// Every GPU the library's code object is loaded on holds its own copy of this array, at its own address, until
+// the process ends.  In host code the array's NAME is only a handle for hipGetSymbolAddress: the address a kernel
+// may use is looked up once per device (noalloc_scratch_for_current_device) and kept in g_noalloc_ptr.
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)STEREO_NOALLOC_MAX_PIXELS * 32 + 256 + (size_t)65536 * 8 + 1024;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+static void *g_noalloc_ptr[64] = {nullptr};
+static std::mutex g_noalloc_mutex;
+
+// Device address of `scratch` on the current device (looked up at the first use on that device; stereo_hip_init
+// does it ahead of time).  No allocation: the array is part of the loaded code object.
+static int noalloc_scratch_for_current_device(void **out) {
+    int dev = 0;
+    SHP_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("device index %d beyond the 64 this library keeps state for", dev); return STEREO_EUNSUPPORTED; }
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_ptr[dev]) {
+        void *ptr = nullptr;
+        SHP_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) { set_error("hipGetSymbolAddress returned a null address for the static scratch"); return STEREO_EHIP; }
+        g_noalloc_ptr[dev] = ptr;
+    }
+    *out = g_noalloc_ptr[dev];
+    return STEREO_OK;
+}
+
 extern "C" {
 
 const char *stereo_hip_last_error(void) { return g_err; }
@@ -409,7 +435,8 @@ int stereo_hip_init(int device) {
     if (n <= 0) { set_error("no HIP device is visible"); return STEREO_EHIP; }
     if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return STEREO_EINVAL; }
     SHP_HIP(hipSetDevice(device));
-    return STEREO_OK;
+    void *unused = nullptr;
+    return noalloc_scratch_for_current_device(&unused);   // so that the first no-allocation call has nothing to look up
 }
 
 int stereo_generate_offsets(int radius, int32_t *out) {
@@ -538,6 +565,37 @@ int stereo_aggregate_wta_dev(const float *d_dsi, const float *d_guide, int H, in
     SHP_TRY(launch_fused_guided(nullptr, nullptr, nullptr, d_dsi, d_guide, STEREO_DT_F32, mean, invden, H, W, dmax,
                                 p->guided_radius, d_begin, d_end, d_keys, nullptr, 0, s));
     return prof.end();
+}
+
+int stereo_compute_disparity_noalloc_dev(const float *d_left, const float *d_right, int H, int W, int dmax,
+                                         const StereoParams *p, int d_begin, int d_end, uint64_t *d_keys,
+                                         void *stream) {
+    if (!d_left || !d_right || !p || !d_keys) { set_error("null pointer"); return STEREO_EINVAL; }
+    SHP_TRY(check_params(p));
+    SHP_TRY(check_image_dims(H, W));
+    if (dmax <= 0) { set_error("dmax must be a positive integer"); return STEREO_EINVAL; }
+    if (d_begin < 0 || d_end > dmax || d_begin > d_end) {
+        set_error("disparity range [%d, %d) outside [0, %d)", d_begin, d_end, dmax);
+        return STEREO_EINVAL;
+    }
+    if ((size_t)H * (size_t)W > (size_t)STEREO_NOALLOC_MAX_PIXELS) {
+        set_error("frame of %d x %d = %zu pixels exceeds the %d pixels the static scratch of the no-allocation entry "
+                  "point holds: use stereo_compute_disparity_dev with a workspace", H, W, (size_t)H * W,
+                  STEREO_NOALLOC_MAX_PIXELS);
+        return STEREO_EINVAL;
+    }
+    {
+        CensusCfg cfg;   // (census radius / weights are judged before the first device call)
+        SHP_TRY(make_census_cfg(p->wct_radius, p->base_weight, &cfg));
+    }
+    const size_t need = fused_ws_layout(H, W, p->wct_radius).total;
+    if (need > NOALLOC_SCRATCH_BYTES) { set_error("static scratch too small: %zu > %zu", need, NOALLOC_SCRATCH_BYTES); return STEREO_EINVAL; }
+    void *ptr = nullptr;
+    SHP_TRY(noalloc_scratch_for_current_device(&ptr));
+    // the same kernels as stereo_compute_disparity_dev, with the device address of this GPU's array as workspace;
+    // every word of it that a kernel reads is written (or cleared) by an earlier kernel of the same call
+    return fused_disparity_dev(d_left, d_right, H, W, dmax, p, d_begin, d_end, ptr, NOALLOC_SCRATCH_BYTES, d_keys, nullptr,
+                               static_cast<hipStream_t>(stream));
 }
 
 int stereo_progress_plan(int H, int W, const StereoParams *p, int n_bands, int32_t *row_end, int *bands_out) {

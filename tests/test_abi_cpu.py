@@ -91,6 +91,9 @@ def test_null_pointers_are_rejected_before_any_device_work():
     assert lib.stereo_compute_disparity_dev(N, N, 8, 8, 4, p, 0, 4, N, 0, N, N) == E
     assert lib.stereo_compute_disparity_dev(N, N, 8, 8, 4, None, 0, 4, N, 0, N, N) == E
     assert lib.stereo_compute_disparity_progress_dev(N, N, 8, 8, 4, p, 0, 4, N, 0, N, 1, N, 1, N) == E
+    assert lib.stereo_compute_disparity_noalloc_dev(N, N, 8, 8, 4, p, 0, 4, N, N) == E
+    assert lib.stereo_wct_cost_volume_dev(N, N, 8, 8, 4, 4, 8.0, N, 0, N, N) == E
+    assert lib.stereo_aggregate_wta_dev(N, N, 8, 8, 4, p, 0, 4, N, 0, N, N) == E
     assert lib.stereo_wait_progress_dev(N, 0, 1, N) == E
     assert lib.stereo_progress_plan(8, 8, None, 1, N, None) == E
     assert lib.stereo_merge_keys_dev(N, N, 4, N) == E
@@ -151,6 +154,18 @@ def test_bad_arguments_are_rejected_before_any_device_work():
     bad_eps = _native.StereoParams(wct_radius=4, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=3,
                                    guided_eps=0.0, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
     assert call(params=bad_eps) == E
+    # the entry point that allocates nothing: the same checks, and frames beyond its static scratch
+    def call_noalloc(h=40, w=60, dmax=8, params=p, d0=0, d1=8):
+        return lib.stereo_compute_disparity_noalloc_dev(ptr, ptr, h, w, dmax, params, d0, d1, ptr, None)
+    assert call_noalloc(d0=5, d1=4) == E and call_noalloc(d1=9) == E and call_noalloc(dmax=0, d1=0) == E
+    assert call_noalloc(h=0) == E and call_noalloc(params=bad_eps) == E
+    assert call_noalloc(h=1025, w=1024) == E and "exceeds" in _native.last_error()
+    assert call_noalloc(params=bad_r) == _native.EUNSUPPORTED
+    # the two-call device entry points
+    assert lib.stereo_wct_cost_volume_dev(ptr, ptr, 40, 60, 0, 4, 8.0, ptr, nbytes.value, ptr, None) == E
+    assert lib.stereo_wct_cost_volume_dev(ptr, ptr, 40, 60, 8, 4, 8.0, ptr, nbytes.value - 1, ptr, None) == E
+    assert lib.stereo_aggregate_wta_dev(ptr, ptr, 40, 60, 8, p, 3, 2, ptr, nbytes.value, ptr, None) == E
+    assert lib.stereo_aggregate_wta_dev(ptr, ptr, 40, 60, 8, p, 0, 8, ptr, nbytes.value - 1, ptr, None) == E
     row_end = (ctypes.c_int32 * 16)()
     n = ctypes.c_int(0)
     assert lib.stereo_progress_plan(40, 60, p, 0, row_end, ctypes.byref(n)) == E
