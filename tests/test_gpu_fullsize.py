@@ -1,0 +1,116 @@
+"""The two large benchmark configurations at their full sizes, through the drop-in Python API:
+
+* 3840 x 2160, dmax 512, census radius 4, guided filter r = 3, eps = 0.0154: a row strip of the full-frame
+  result against the CPU oracle, and the 8-way disparity split of the multi-GPU benchmark merged by the
+  (cost, d) minimum against the unsharded frame (bit for bit);
+* 7680 x 4320, dmax 256, census radius 8 with the uint8-quantised median (bit-exact), the Gaussian and the
+  bilateral filter (1e-5 relative, disparity mismatches gap-checked): a row strip against
+  oracle.aggregate_and_wta on oracle.wct_cost_volume(radius=8).
+
+The oracle only sees a strip (plus the rows its windows reach), sized to finish in seconds.  The uint8 median
+quantises every cost layer with the minimum and maximum of the WHOLE layer (reference filters.py:139-166), which
+a strip cannot know in general; the 8K pair therefore repeats a 40-row pattern down the frame, so that any 40
+consecutive valid rows hold every cost value of the layer and the strip's range is the frame's."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import TOL, assert_wta_matches, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair_4k():
+    from synth import synth_pair_gray
+    left, right, _ = synth_pair_gray(2160, 3840, 512, 3840)   # bench.py's "4k" workload
+    return left, right
+
+
+def test_4k_strip_matches_oracle(oracle, pair_4k):
+    import stereo
+    left, right = pair_4k
+    d, c = stereo.compute_disparity(left, right, 512, guided_eps=0.0154, show_progress=False)
+    assert d.shape == (2160, 3840) and d.dtype == np.int32 and c.dtype == np.float32
+    y0, y1, halo = 1290, 1350, 2 * 3 + 4      # 60 rows that straddle a tile border (30-row tiles)
+    lo, hi = y0 - halo, y1 + halo
+    dref, cref = oracle.compute_disparity_allcores(np.ascontiguousarray(left[lo:hi]), np.ascontiguousarray(right[lo:hi]),
+                                                   512, wct_radius=4, radius=3, eps=0.0154)
+    dref, cref = dref[halo:-halo], cref[halo:-halo]
+    ds, cs = d[y0:y1], c[y0:y1]
+    assert rel_err(cs, cref) <= TOL
+    assert np.mean(ds == dref) >= 0.999
+    bad = ds != dref   # every mismatch is a near-tie of the two winning costs
+    assert np.all(np.abs(cs[bad] - cref[bad]) <= TOL * np.maximum(1.0, np.abs(cref[bad])))
+    # the frame's last rows and columns (clipped windows, partial tiles) against the oracle as well
+    lo = 2160 - 40 - halo
+    dref, cref = oracle.compute_disparity_allcores(np.ascontiguousarray(left[lo:]), np.ascontiguousarray(right[lo:]),
+                                                   512, wct_radius=4, radius=3, eps=0.0154)
+    ds, cs = d[-40:], c[-40:]
+    assert rel_err(cs, cref[-40:]) <= TOL and np.mean(ds == dref[-40:]) >= 0.999
+
+
+def test_4k_eight_disparity_shards_merge_bit_exact(pair_4k):
+    """The split bench.py --gpus 8 --workload 4k uses: rank r searches [r * 512 / 8, (r + 1) * 512 / 8)."""
+    import sharding
+    import stereo
+    left, right = pair_4k
+    run = lambda **kw: stereo.compute_disparity(left, right, 512, guided_eps=0.0154, show_progress=False, **kw)
+    d0, c0 = run()
+    best_c = np.full(c0.shape, np.inf, dtype=np.float32)
+    best_d = np.zeros(d0.shape, dtype=np.int32)
+    for rank in range(8):
+        a, b = sharding.shard_range(512, 8, rank)
+        dd, cc = run(d_begin=a, d_end=b)
+        better = cc < best_c          # shards arrive in ascending d: strict '<' keeps the lower disparity
+        best_c = np.where(better, cc, best_c)
+        best_d[better] = dd[better]
+    assert np.array_equal(best_d, d0) and np.array_equal(best_c, c0)
+
+
+PERIOD = 40
+
+
+@pytest.fixture(scope="module")
+def pair_8k():
+    """7680 x 4320 pair whose rows repeat with period 40 (see the module text), and the oracle's cost volume of
+    the strip that the three filter tests share."""
+    from synth import synth_pair_gray
+    l40, r40, _ = synth_pair_gray(PERIOD, 7680, 256, 7680)
+    reps = 4320 // PERIOD
+    return np.ascontiguousarray(np.tile(l40, (reps, 1))), np.ascontiguousarray(np.tile(r40, (reps, 1)))
+
+
+STRIP_Y0, STRIP_ROWS, STRIP_HALO = 2000, PERIOD, 8 + 3     # census radius + filter radius
+
+
+@pytest.fixture(scope="module")
+def strip_volume_8k(oracle, pair_8k):
+    left, right = pair_8k
+    lo, hi = STRIP_Y0 - STRIP_HALO, STRIP_Y0 + STRIP_ROWS + STRIP_HALO
+    ls, rs = np.ascontiguousarray(left[lo:hi]), np.ascontiguousarray(right[lo:hi])
+    threads = oracle.max_threads()
+    return ls, oracle.wct_cost_volume(ls, rs, 256, radius=8, parallel_chunk=max(8, threads), threads=threads)
+
+
+@pytest.mark.parametrize("filt", ["median", "gaussian", "bilateral"])
+def test_8k_strip_matches_oracle(oracle, pair_8k, strip_volume_8k, filt):
+    import stereo
+    left, right = pair_8k
+    d, c = stereo.compute_disparity(left, right, 256, wct_radius=8, filter_type=filt, median_radius=3, gaussian_sigma=1.0,
+                                    bilateral_sigma=1.0, show_progress=False)
+    assert d.shape == (4320, 7680)
+    guide, dsi = strip_volume_8k
+    threads = oracle.max_threads()
+    kind, radius, par = {"median": (oracle.FILTER_MEDIAN_U8Q, 3, 0.0), "gaussian": (oracle.FILTER_GAUSSIAN, 0, 1.0),
+                         "bilateral": (oracle.FILTER_BILATERAL, 0, 1.0)}[filt]
+    dref, cref, layers = oracle.aggregate_and_wta(dsi, guide, kind, radius, par, want_layers=True, threads=threads)
+    sl = slice(STRIP_HALO, STRIP_HALO + STRIP_ROWS)
+    dref, cref, layers = dref[sl], cref[sl], layers[:, sl]
+    ds, cs = d[STRIP_Y0:STRIP_Y0 + STRIP_ROWS], c[STRIP_Y0:STRIP_Y0 + STRIP_ROWS]
+    if filt == "median":
+        assert np.array_equal(ds, dref) and np.array_equal(cs, cref)
+    else:
+        assert_wta_matches(ds, cs, dref, cref, layers_ref=layers)
+    # the pattern repeats down the frame: so must the result, away from the first and last rows
+    again = slice(STRIP_Y0 + 25 * PERIOD, STRIP_Y0 + 26 * PERIOD)
+    assert np.array_equal(d[again], ds) and np.array_equal(c[again], cs)
