@@ -8,50 +8,93 @@
 namespace shp {
 
 // ---- integral image -----------------------------------------------------------------------------
-// Column pass: one lane per column, rows in sequence (the same association order as the
-// reference's column cumulative sum), coalesced along x.
+// guided_filter.py:21-47: cumulative sum down the columns, then along the rows, into a zero-bordered
+// (H+1, W+1) table.  Both passes are parallel scans:
+//  * columns: the rows are cut into chunks of SCAN_ROWS; every (chunk, column) sums its rows (coalesced along x),
+//    and a second sweep adds up the totals of the chunks above (its carry) and writes the running sums from there;
+//  * rows: one wavefront per row walks the row in 64-column segments, each segment an inclusive wave scan in
+//    registers (row_shr / row_bcast lane shifts, no LDS) plus the carry of the segments before it.
+// The sums associate differently from the reference's sequential loops (chunk carries, scan trees), so a table of
+// arbitrary float64 values agrees to rounding (relative 1e-12 in the tests) and a table of integer-valued inputs,
+// where every partial sum is exact, bit for bit.  Non-finite inputs give the reference's pattern: a prefix that
+// holds a NaN, or infinities of both signs, is NaN in any association.
+constexpr int SCAN_ROWS = 64;
+
 template <typename T>
-__global__ __launch_bounds__(64) void integral_cols_kernel(const T *__restrict__ img, int H, int W,
-                                                           double *__restrict__ tmp) {
-    int x = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void integral_col_partial_kernel(const T *__restrict__ img, int H, int W,
+                                                                   double *__restrict__ part) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= W) return;
+    const int y0 = blockIdx.y * SCAN_ROWS, y1 = min(H, y0 + SCAN_ROWS);
     double s = 0.0;
-    for (int y = 0; y < H; ++y) {
+#pragma unroll 8
+    for (int y = y0; y < y1; ++y) s = s + (double)img[(size_t)y * W + x];
+    part[(size_t)blockIdx.y * W + x] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void integral_col_scan_kernel(const T *__restrict__ img, int H, int W,
+                                                                const double *__restrict__ part,
+                                                                double *__restrict__ tmp) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const int y0 = blockIdx.y * SCAN_ROWS, y1 = min(H, y0 + SCAN_ROWS);
+    double s = 0.0;   // carry: the totals of the chunks above, added top to bottom
+    for (int c = 0; c < (int)blockIdx.y; ++c) s = s + part[(size_t)c * W + x];
+#pragma unroll 8
+    for (int y = y0; y < y1; ++y) {
         s = s + (double)img[(size_t)y * W + x];
         tmp[(size_t)y * W + x] = s;
     }
 }
 
-// Row pass: the running sum along a row must add the columns strictly left to right to give the
-// reference's bits for any float64 input (guided_filter.py:42-46), so one lane walks one row.  A
-// wavefront owns 64 rows; 64x64 tiles go through LDS so that global loads and stores stay
-// coalesced along x while each lane scans its own row of the tile.  Writes the zero-bordered
-// (H+1, W+1) table.
-__global__ __launch_bounds__(64) void integral_rows_kernel(const double *__restrict__ tmp, int H, int W,
-                                                           double *__restrict__ integral) {
-    __shared__ double tile[64][65];
-    const int lane = threadIdx.x;
-    const int r0 = blockIdx.x * 64;
-    const int rows = min(64, H - r0);
+// lane shift of a float64 through two 32-bit DPP moves; lanes without a source (and rows outside ROW_MASK) read 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over the 64 lanes of a wavefront
+__device__ __forceinline__ double wave_inclusive_scan(double v) {
+    v = v + dpp_shift_f64<0x111, 0xf>(v);   // row_shr:1
+    v = v + dpp_shift_f64<0x112, 0xf>(v);   // row_shr:2
+    v = v + dpp_shift_f64<0x114, 0xf>(v);   // row_shr:4
+    v = v + dpp_shift_f64<0x118, 0xf>(v);   // row_shr:8   -> scans of the four 16-lane rows
+    v = v + dpp_shift_f64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = v + dpp_shift_f64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// Row pass: tmp (column sums) -> integral, one wavefront per row, four segments of 64 columns in flight.
+__global__ __launch_bounds__(256) void integral_row_scan_kernel(const double *__restrict__ tmp, int H, int W,
+                                                                double *__restrict__ integral) {
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
     const size_t IW = (size_t)W + 1;
     if (blockIdx.x == 0)
-        for (int x = lane; x <= W; x += 64) integral[x] = 0.0;
-    if (lane < rows) integral[(size_t)(r0 + lane + 1) * IW] = 0.0;
+        for (int x = threadIdx.x; x <= W; x += 256) integral[x] = 0.0;   // the zero row above the image
+    if (y >= H) return;
+    const double *src = tmp + (size_t)y * W;
+    double *dst = integral + (size_t)(y + 1) * IW;
+    if (lane == 0) dst[0] = 0.0;
     double carry = 0.0;
-    for (int x0 = 0; x0 < W; x0 += 64) {
-        const int cols = min(64, W - x0);
-        if (lane < cols)
-            for (int i = 0; i < rows; ++i) tile[i][lane] = tmp[(size_t)(r0 + i) * W + x0 + lane];
-        __syncthreads();
-        if (lane < rows)
-            for (int j = 0; j < cols; ++j) {
-                carry = carry + tile[lane][j];
-                tile[lane][j] = carry;
-            }
-        __syncthreads();
-        if (lane < cols)
-            for (int i = 0; i < rows; ++i) integral[(size_t)(r0 + i + 1) * IW + x0 + lane + 1] = tile[i][lane];
-        __syncthreads();
+    for (int x0 = 0; x0 < W; x0 += 256) {
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + k * 64 + lane;
+            v[k] = x < W ? src[x] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = wave_inclusive_scan(v[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + k * 64 + lane;
+            const double out = carry + v[k];
+            if (x < W) dst[x + 1] = out;
+            carry = __shfl(out, 63);
+        }
     }
 }
 
@@ -78,11 +121,18 @@ __global__ __launch_bounds__(256) void box_from_integral_kernel(const double *__
     out[(size_t)y * W + x] = s / ar;
 }
 
+// d_tmp: H * W doubles; d_integral: (H + 1) * (W + 1) doubles, whose first n_chunks * W entries double as the
+// scratch of the column pass (it is complete before the row pass writes the table)
 template <typename T>
 static int launch_integral_t(const T *img, int H, int W, double *tmp, double *integral, hipStream_t s) {
-    hipLaunchKernelGGL(integral_cols_kernel<T>, dim3(ceil_div(W, 64)), dim3(64), 0, s, img, H, W, tmp);
+    const int n_chunks = ceil_div(H, SCAN_ROWS);
+    double *part = integral;
+    dim3 grid(ceil_div(W, 256), n_chunks);
+    hipLaunchKernelGGL(integral_col_partial_kernel<T>, grid, dim3(256), 0, s, img, H, W, part);
     SHP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(integral_rows_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, s, tmp, H, W, integral);
+    hipLaunchKernelGGL(integral_col_scan_kernel<T>, grid, dim3(256), 0, s, img, H, W, part, tmp);
+    SHP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(integral_row_scan_kernel, dim3(ceil_div(H, 4)), dim3(256), 0, s, tmp, H, W, integral);
     SHP_LAUNCH_CHECK();
     return STEREO_OK;
 }
