@@ -133,7 +133,7 @@ int stereo_fused_workspace_bytes(int height, int width, const StereoParams *para
  * packed key per pixel: (order-preserving uint32 image of the float32 min cost) << 32 | d, so
  * that an unsigned 64-bit MIN over keys of different disparity shards is the reference's
  * "lowest cost, ties to the lowest disparity" rule (stereo.py:167-170).
- * Covers the guided filter (radius 1..4), the uint8-quantised median (radius 1..4) and the
+ * Covers the guided filter (radius 1..8), the uint8-quantised median (radius 1..4) and the
  * Gaussian / bilateral filters (ceil(3 sigma) <= 4); other parameters return STEREO_EUNSUPPORTED
  * (the host entry point falls back to the layer-at-a-time path for them). */
 int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int height, int width, int dmax,
@@ -141,7 +141,7 @@ int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int 
                                  size_t workspace_bytes, uint64_t *d_keys, void *stream);
 /* The two-call form of the path on device buffers, the data flow the reference's public API defines:
  * census.compute_wct_cost_volume (census.py:205-269) writes d_dsi[H][W][dmax] float32 (D innermost, census.py:250)
- * from float32 device images, and stereo.aggregate_and_wta (stereo.py:94-174, guided filter, radius 1..4,
+ * from float32 device images, and stereo.aggregate_and_wta (stereo.py:94-174, guided filter, radius 1..8,
  * float32 guide, finite costs) reads it back layer by layer (stereo.py:146) and writes one packed key per pixel.
  * d_workspace / workspace_bytes as for stereo_compute_disparity_dev (params->wct_radius sizes it). */
 int stereo_wct_cost_volume_dev(const float *d_left, const float *d_right, int height, int width, int dmax, int radius,

@@ -187,7 +187,7 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
     SHP_TRY(launch_census_pack_pair(d_left, d_right, STEREO_DT_F32, H, W, p->wct_radius, lw, rw, s));
     if (p->filter_kind == STEREO_FILTER_GUIDED) {
         if (!fused_guided_supported(p->guided_radius)) {
-            set_error("fused guided path supports radius 1..4, got %d", p->guided_radius);
+            set_error("fused guided path supports radius 1..8, got %d", p->guided_radius);
             return STEREO_EUNSUPPORTED;
         }
         float *gmax = reinterpret_cast<float *>(base + L.off_gmax);
@@ -548,7 +548,7 @@ int stereo_aggregate_wta_dev(const float *d_dsi, const float *d_guide, int H, in
     if (dmax <= 0) { set_error("dsi must have at least one disparity layer"); return STEREO_EINVAL; }
     if (d_begin < 0 || d_end > dmax || d_begin > d_end) { set_error("bad disparity range"); return STEREO_EINVAL; }
     if (p->filter_kind != STEREO_FILTER_GUIDED || !fused_guided_supported(p->guided_radius)) {
-        set_error("the device entry point aggregates with the guided filter, radius 1..4");
+        set_error("the device entry point aggregates with the guided filter, radius 1..8");
         return STEREO_EUNSUPPORTED;
     }
     FusedWs L = fused_ws_layout(H, W, p->wct_radius);

@@ -357,8 +357,14 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_kernel(FusedArgs a) {
 constexpr int FG_TH = 32;
 constexpr int FG_NW = 16;
 
+// Radii above 4 keep rings of up to 17 rows per lane: they run eight wavefronts per workgroup (two per SIMD, 256
+// registers each) instead of sixteen.
+template <int RG>
+struct FusedGeometry { static constexpr int NW = RG <= 4 ? FG_NW : 8; };
+
 template <int RG, int SRC, bool INT_UNITS, typename GT>
 static int launch_fused_t(const FusedArgs &a, hipStream_t s) {
+    constexpr int FG_NW = FusedGeometry<RG>::NW;
     constexpr int WIN = 2 * RG + 1, NI = FG_TH + 4 * RG, NJ = FG_TH + 2 * RG, TWV = 64 - 4 * RG, EXN = 64 + 2 * RG;
     using WordT = typename std::conditional<SRC == SRC_CENSUS64, uint64_t, uint32_t>::type;
     using PT = typename std::conditional<INT_UNITS, uint32_t, double>::type;
@@ -393,7 +399,7 @@ static int launch_fused_rg(const FusedArgs &a, int src, bool int_units, int guid
     return launch_fused_t<RG, SRC_CENSUS64, false, float>(a, s);
 }
 
-bool fused_guided_supported(int guided_radius) { return guided_radius >= 1 && guided_radius <= 4; }
+bool fused_guided_supported(int guided_radius) { return guided_radius >= 1 && guided_radius <= 8; }
 
 int launch_fused_guided(const void *d_lw, const void *d_rw, const CensusCfg *cfg, const float *d_dsi,
                         const void *d_guide, int guide_dtype, const double *d_mean, const double *d_invden,
@@ -415,8 +421,12 @@ int launch_fused_guided(const void *d_lw, const void *d_rw, const CensusCfg *cfg
         case 2: return launch_fused_rg<2>(a, src, int_units, guide_dtype, s);
         case 3: return launch_fused_rg<3>(a, src, int_units, guide_dtype, s);
         case 4: return launch_fused_rg<4>(a, src, int_units, guide_dtype, s);
+        case 5: return launch_fused_rg<5>(a, src, int_units, guide_dtype, s);
+        case 6: return launch_fused_rg<6>(a, src, int_units, guide_dtype, s);
+        case 7: return launch_fused_rg<7>(a, src, int_units, guide_dtype, s);
+        case 8: return launch_fused_rg<8>(a, src, int_units, guide_dtype, s);
         default:
-            set_error("fused guided kernel supports radius 1..4, got %d", guided_radius);
+            set_error("fused guided kernel supports radius 1..8, got %d", guided_radius);
             return STEREO_EUNSUPPORTED;
     }
 }

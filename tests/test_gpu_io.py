@@ -190,7 +190,7 @@ def test_eval_npz_tool(gold, tmp_path, capsys):
 
 
 @pytest.mark.parametrize("filt,kw", [("guided", {}), ("median", {}), ("gaussian", {"gaussian_sigma": 0.8}),
-                                     ("guided", {"guided_radius": 6})])
+                                     ("guided", {"guided_radius": 6}), ("guided", {"guided_radius": 9})])
 def test_compute_disparity_sharded_equals_plain(filt, kw):
     """The multi-GPU entry point of the package on one rank (no process group): same result as
     compute_disparity; parameters without a fused kernel are refused so that the caller can fall back."""
@@ -198,7 +198,7 @@ def test_compute_disparity_sharded_equals_plain(filt, kw):
     from synth import synth_pair_gray
 
     left, right, _ = synth_pair_gray(150, 260, 40, seed=9)
-    if kw.get("guided_radius") == 6:
+    if kw.get("guided_radius") == 9:   # guided radii above 8 have no fused kernel
         with pytest.raises(NotImplementedError):
             stereo.compute_disparity_sharded(left, right, 40, world=1, rank=0, filter_type=filt, **kw)
         return

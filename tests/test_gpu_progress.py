@@ -140,7 +140,7 @@ def test_device_entry_points_reject_bad_arguments():
     assert call(dd=0, d1=0) == _native.EINVAL
     assert call(hh=0) == _native.EINVAL
     assert call(left=None) == _native.EINVAL
-    big_r = _native.StereoParams(wct_radius=4, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=7,
+    big_r = _native.StereoParams(wct_radius=4, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=9,
                                  guided_eps=0.0154, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
     assert call(p=big_r) == _native.EUNSUPPORTED
     bad_r = _native.StereoParams(wct_radius=9, base_weight=8.0, filter_kind=_native.FILTER_GUIDED, guided_radius=3,
