@@ -302,36 +302,38 @@ __device__ __forceinline__ void pair_disparity_pass(
                     br[j][k2] = bv;
                 }
                 if (STEADY || i >= 2 * HALO) {
-                    // 6. sums over the 2r + 1 stage-1 columns starting in each slot
+                    // 6. sums over the 2r + 1 stage-1 columns starting in each slot.  Both columns of a lane are
+                    //    evaluated at ONE reference guide value c = G(2l): E = A c + B in float64, and the window sum
+                    //    of A_j G(x) + B_j is  sum E_j + sum A_j (G(x) - c_j)  with c_j the reference of column j's lane.
+                    //    Every term is small where the guide is locally smooth and every difference is between guide
+                    //    values a few columns apart, so float32 lane chains suffice; and because a lane's two columns
+                    //    share their reference, the correction needs one product per LANE of the window (with the
+                    //    pair sum A_even + A_odd) instead of one per column.
                     const int o = i - 2 * HALO;
-                    f2 E, av[RG + 1];
-                    E.x = (float)fma(A[0], (double)gp[0].x, B[0]);  // each column's own-guide output
-                    E.y = (float)fma(A[1], (double)gp[0].y, B[1]);
-                    av[0].x = (float)A[0];
-                    av[0].y = (float)A[1];
+                    f2 E, P[RG + 1];
+                    const double cref = (double)gp[0].x;
+                    E.x = (float)fma(A[0], cref, B[0]);
+                    E.y = (float)fma(A[1], cref, B[1]);
+                    const float a0 = (float)A[0], a1 = (float)A[1];
+                    P[0] = f2{a0, a0 + a1};    // (A of the lane's even column, A of the pair)
                     float ee = E.x, eo = E.y, eer = E.x, eor = E.y;
 #pragma unroll
                     for (int u = 1; u <= RG; ++u) {
                         eer = ee; eor = eo;
                         ee = E.x + dpp_f<DPP_WAVE_SHL1>(ee);
                         eo = E.y + dpp_f<DPP_WAVE_SHL1>(eo);
-                        av[u].x = dpp_mov_f<DPP_WAVE_SHL1>(av[u - 1].x);   // A of tile column 2(l + u)
-                        av[u].y = dpp_mov_f<DPP_WAVE_SHL1>(av[u - 1].y);   // A of tile column 2(l + u) + 1
+                        P[u].x = dpp_mov_f<DPP_WAVE_SHL1>(P[u - 1].x);
+                        P[u].y = dpp_mov_f<DPP_WAVE_SHL1>(P[u - 1].y);
                     }
                     f2 se;
                     se.x = ee + eor;
                     se.y = eo + dpp_f<DPP_WAVE_SHL1>(eer);
-                    // sum_j A_j * (G(x) - G_j) over the other 2r columns of each window.  Slot 0's window is
-                    // columns 2l .. 2l + 2r (its own term vanishes), slot 1's is 2l + 1 .. 2l + 2r + 1.
-                    f2 acc0 = av[0] * (gp[0].xx - gp[0]);
-                    f2 acc1 = av[1] * (gp[0].yy - gp[1]);
+                    // Slot 0 (x = 2l, G(x) = c of its own lane): lanes l+1 .. l+r-1 whole, the even column of lane l+r.
+                    // Slot 1 (x = 2l+1): its own column, lanes l+1 .. l+r whole.
+                    f2 dsum = f2{0.f, a1 * (gp[0].y - gp[0].x)};
 #pragma unroll
-                    for (int u = 1; u < RG; ++u) acc0 = fma2(av[u], gp[0].xx - gp[u], acc0);
-#pragma unroll
-                    for (int u = 2; u <= RG; ++u) acc1 = fma2(av[u], gp[0].yy - gp[u], acc1);
-                    f2 dsum;
-                    dsum.x = fmaf(av[RG].x, gp[0].x - gp[RG].x, acc0.x + acc0.y);
-                    dsum.y = acc1.x + acc1.y;
+                    for (int u = 1; u < RG; ++u) dsum = fma2(gp[0] - gp[u].xx, P[u].yy, dsum);
+                    dsum = fma2(gp[0] - gp[RG].xx, P[RG], dsum);
                     // 7. q and the running WTA.  a and b already carry the cost unit.  Full windows: one multiply by
                     //    fl(1 / (2r+1)^2), whose relative error is below 2^-25 for r = 1..4, so a window of equal
                     //    costs c (t32 = (2r+1)^2 c exactly) rounds to exactly c; clipped windows: one Newton step on
