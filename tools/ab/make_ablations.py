@@ -21,14 +21,11 @@ def variant(name, text):
         text = text.replace(a, b)
     if name == "base":
         pass
-    elif name == "nocorr":      # no A * (G(x) - G_j) correction and no lane shifts of A
-        rep("const f2 t32 = se + dsum;", "const f2 t32 = se + f2{av[0].x, av[0].y};")
-        a0 = text.index("                        av[u].x = dpp_mov_f<DPP_WAVE_SHL1>(av[u - 1].x);")
-        a1 = text.index("                    }\n                    f2 se;")
-        text = text[:a0] + text[a1:]
-        a0 = text.index("                    f2 acc0 = av[0] * (gp[0].xx - gp[0]);")
-        a1 = text.index("                    // 7. q and the running WTA.")
-        text = text[:a0] + text[a1:]
+    elif name == "nocorr":      # no A * (G(x) - c) correction and no lane shifts of A
+        rep("                        P[u].x = dpp_mov_f<DPP_WAVE_SHL1>(P[u - 1].x);\n", "")
+        rep("                        P[u].y = dpp_mov_f<DPP_WAVE_SHL1>(P[u - 1].y);\n", "")
+        rep("    for (int u = 1; u < RG; ++u) dsum = fma2(gp[0] - gp[u].xx, P[u].yy, dsum);", "    for (int u = 1; u < 1; ++u) {}")
+        rep("                    dsum = fma2(gp[0] - gp[RG].xx, P[RG], dsum);", "                    dsum += P[0];")
     elif name == "nof2":        # no float32 g_lo * p chain
         rep("sf[0] = ef_ + dpp_f<DPP_WAVE_SHR1>(ofr);", "sf[0] = F2.x;")
         rep("sf[1] = of_ + efr;", "sf[1] = F2.y;")
@@ -52,25 +49,21 @@ def variant(name, text):
         text = text[:a0] + blk + text[a1:]
         rep("    double A[2] = {0.0, 0.0}, B[2] = {0.0, 0.0};", "    float A[2] = {0.f, 0.f}, B[2] = {0.f, 0.f};")
         rep("    double ar[2][WIN], br[2][WIN];", "    float ar[2][WIN], br[2][WIN];")
-        rep("E.x = (float)fma(A[0], (double)gp[0].x, B[0]);", "E.x = fmaf(A[0], gp[0].x, B[0]);")
-        rep("E.y = (float)fma(A[1], (double)gp[0].y, B[1]);", "E.y = fmaf(A[1], gp[0].y, B[1]);")
+        rep("const double cref = (double)gp[0].x;", "const float cref = gp[0].x;")
+        rep("E.x = (float)fma(A[0], cref, B[0]);", "E.x = fmaf(A[0], cref, B[0]);")
+        rep("E.y = (float)fma(A[1], cref, B[1]);", "E.y = fmaf(A[1], cref, B[1]);")
         rep("const double mG[2] = {cur.mG[0], cur.mG[1]};", "const float mG[2] = {(float)cur.mG[0], (float)cur.mG[1]};")
     elif name == "nokey":       # no key update
         a0 = text.index("                        const unsigned long long key = ((unsigned long long)ordered_bits(tf) << 32)")
         a1 = text.index("                    }\n                }\n            }\n            cur = nxt;")
         text = text[:a0] + "                        " + KEEP.format("tf") + "\n" + text[a1:]
-    elif name == "scalarcorr":  # correction written on scalars instead of packed pairs
-        a0 = text.index("                    f2 acc0 = av[0] * (gp[0].xx - gp[0]);")
-        a1 = text.index("                    // 7. q and the running WTA.")
-        new = '''                    float c0 = av[0].y * (gp[0].x - gp[0].y), c1 = 0.f;
-#pragma unroll
-                    for (int u = 1; u < RG; ++u) { c0 = fmaf(av[u].x, gp[0].x - gp[u].x, c0); c0 = fmaf(av[u].y, gp[0].x - gp[u].y, c0); }
-                    c0 = fmaf(av[RG].x, gp[0].x - gp[RG].x, c0);
-#pragma unroll
-                    for (int u = 1; u <= RG; ++u) { c1 = fmaf(av[u].x, gp[0].y - gp[u].x, c1); c1 = fmaf(av[u].y, gp[0].y - gp[u].y, c1); }
-                    f2 dsum = {c0, c1};
-'''
-        text = text[:a0] + new + text[a1:]
+    elif name == "noab":        # a, b replaced by trivial values (no float64 arithmetic, no conversions)
+        a0 = text.index("                    const double s1d = (double)s1[j];")
+        a1 = text.index("                    A[j] += av;")
+        text = text[:a0] + "                    const double av = __hiloint2double((int)s1[j], si[j]), bv = __hiloint2double(__float_as_int(sf[j]), (int)s1[j]);\n" + text[a1:]
+    elif name == "novert2":     # no vertical running sums of a, b
+        rep("                        A[j] -= ar[j][k2];\n", "")
+        rep("                        B[j] -= br[j][k2];\n", "")
     elif name == "nocost":      # no census cost (p = lane constant)
         rep("const uint32_t fs = field_sum((WordT)(cur.L[j] ^ Rcur[j]));", "const uint32_t fs = (uint32_t)cur.L[j] & 127u;")
     else:
@@ -79,7 +72,7 @@ def variant(name, text):
 
 
 def main():
-    names = sys.argv[1:] or ["base", "nocorr", "nof2", "noechain", "nodpp1", "f32ab", "nokey", "nocost"]
+    names = sys.argv[1:] or ["base", "nocorr", "nof2", "noechain", "nodpp1", "f32ab", "nokey", "nocost", "noab", "novert2"]
     src = open(SRC).read()
     objs = [os.path.join(PKG, "csrc", "obj", f) for f in os.listdir(os.path.join(PKG, "csrc", "obj"))
             if f.endswith(".o") and f != "guided_pair.o"]
