@@ -4,7 +4,10 @@ Same public functions, arguments and error behaviour as /root/reference/filters.
 `opencv` methods do not call OpenCV: the median reproduces the reference's own uint8
 quantisation (filters.py:139-166) followed by an exact uint8 median with replicated borders and
 the reference's rescale (filters.py:177-180); the Gaussian evaluates the reference's 2-D
-float32 kernel with reflect-101 borders (filters.py:191-204).
+float32 kernel with reflect-101 borders (filters.py:191-204).  Both are checked against the
+reference's own formulas; against OpenCV itself (cv2.medianBlur, cv2.GaussianBlur with its
+separable kernel) they are not, because OpenCV is not available where this was built and the
+reference holds no test or fixture for those calls.
 """
 from __future__ import annotations
 

@@ -130,6 +130,11 @@ def aggregate_and_wta(
                                 median_block_rows, gaussian_sigma, bilateral_sigma)
     if dmax == 0 or height == 0 or width == 0:
         return disparity, min_cost
+    if dsi.dtype == np.uint8 and params.filter_kind == _native.FILTER_MEDIAN_U8Q:
+        # The reference hands uint8 layers to the byte median as they are, without its min/max
+        # quantisation (filters.py:158-161), and returns the bytes as float32: that is the exact
+        # median of the window with replicated borders.
+        params.filter_kind = _native.FILTER_MEDIAN
     dsi_f = np.ascontiguousarray(dsi, dtype=np.float32)
     if guide.dtype == np.float32:
         g, gdt = np.ascontiguousarray(guide), _native.DT_F32
@@ -440,7 +445,8 @@ def _compute_pbm_rms(disparity: np.ndarray, ground_truth: np.ndarray, valid_mask
     """PBM (percent of valid pixels with |d - gt| > threshold) and RMS over pixels whose ground
     truth is finite and whose mask is set  (reference stereo.py:532-577).  One GPU reduction;
     the counts are exact, the squared differences are float32 like the reference's and are
-    summed in float64."""
+    summed in float64, where NumPy's mean of a float32 array sums pairwise in float32: the rms
+    agrees with the reference's to about 1e-7 relative, not to the last bit."""
     disparity, ground_truth, valid_mask = np.asarray(disparity), np.asarray(ground_truth), np.asarray(valid_mask)
     if disparity.shape != ground_truth.shape:
         raise ValueError("disparity and ground_truth sizes differ")

@@ -358,6 +358,26 @@ def test_filters_through_wta_golden(oracle):
     assert_wta_matches(d, c, g["disp_bilateral"], g["cost_bilateral"], lay, min_agree=0.95)
 
 
+def test_uint8_volume_median_skips_the_quantisation():
+    """A uint8 layer goes to the byte median as it is (reference filters.py:158-161), so the result is the
+    exact median of the bytes (replicated borders), not the min/max-quantised one.  Pinned against
+    scipy.ndimage.median_filter, which the reference's `scipy` method calls with the same border rule."""
+    import stereo
+    from scipy.ndimage import median_filter as nd_median
+    rng = np.random.default_rng(77)
+    dsi = rng.integers(3, 200, size=(37, 53, 9), dtype=np.uint8)   # range far from 0..255: quantising would rescale
+    guide = rng.random((37, 53), dtype=np.float32)
+    best_c = np.full(dsi.shape[:2], np.inf, np.float32)
+    best_d = np.zeros(dsi.shape[:2], np.int32)
+    for k in range(dsi.shape[2]):
+        f = nd_median(dsi[:, :, k], size=7, mode="nearest").astype(np.float32)
+        better = f < best_c
+        best_c = np.where(better, f, best_c)
+        best_d = np.where(better, k, best_d)
+    d, c = stereo.aggregate_and_wta(dsi, guide, 3, 0.0154, filter_type="median", median_radius=3)
+    assert np.array_equal(d, best_d) and np.array_equal(c, best_c)
+
+
 def test_radius8_filters_fused_golden(oracle):
     """The 8K benchmark configuration in miniature: census radius 8 with median / gaussian / bilateral."""
     import stereo

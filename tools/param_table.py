@@ -17,7 +17,8 @@ CASES = [
     ("guided r=3 eps=0.005 (below the fast kernels' eps limit)", dict(guided_eps=0.005)),
     ("guided r=1", dict(guided_radius=1, guided_eps=0.0154)),
     ("guided r=4", dict(guided_radius=4, guided_eps=0.0154)),
-    ("guided r=6 (no fused kernel)", dict(guided_radius=6, guided_eps=0.0154)),
+    ("guided r=6 (float64 fused kernel)", dict(guided_radius=6, guided_eps=0.0154)),
+    ("guided r=9 (no fused kernel)", dict(guided_radius=9, guided_eps=0.0154)),
     ("census radius 8, guided r=3", dict(wct_radius=8, guided_eps=0.0154)),
     ("base_weight 3.3 (weights not exactly summable), guided r=3", dict(base_weight=3.3, guided_eps=0.0154)),
     ("median r=3 opencv", dict(filter_type="median")),

@@ -27,4 +27,5 @@ timeout -k 10 300 python bench.py --workload 4k --steps 10 --warmup 3 --no-cpu-b
 for f in guided median gaussian bilateral; do
   timeout -k 10 300 python bench.py --workload 8k --filter $f --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/config5_${f}_8k_bench_line.json" 2> "$OUT/8k_$f.err" || exit 1
 done
+timeout -k 10 600 python tools/param_table.py > "$OUT/param_table.txt" 2> "$OUT/param_table.err" || exit 1
 echo done
