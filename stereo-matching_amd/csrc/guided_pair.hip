@@ -51,6 +51,13 @@ using Pair = T __attribute__((ext_vector_type(2)));  // the two slots of a lane,
 // vector instruction costs one issue slot, so a packed instruction halves the cost of the pair.
 using f2 = Pair<float>;
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// {a.y * b.x + c.y, a.y * b.y + c.y}: the high halves of a and c serve both results.  Written as the instruction
+// with its operand selects: from the vector expression the compiler first copies a.y and c.y into low halves.
+__device__ __forceinline__ f2 fma2_hi(f2 a, f2 b, f2 c) {
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // Tile column c inside a de-interleaved 128-column LDS row: even columns first, then odd ones.  Lane l
 // owns columns 2l and 2l + 1; with this order the lanes' accesses to either parity are consecutive
@@ -87,6 +94,14 @@ __device__ __forceinline__ void pair_disparity_pass(
     const int iv_lo = max(R - (ty0 - HALO), 0), iv_hi = min(H - R - (ty0 - HALO), NI);
     const int ii_lo = max(-(ty0 - HALO), 0), ii_hi = min(H - (ty0 - HALO), NI);
 
+    // the disparity as the low half of every key of the pass: held in one vector register, so that a key is that
+    // register and the one above it instead of a fresh copy of the scalar per key
+    uint32_t d_lane = (uint32_t)d;
+    asm volatile("" : "+v"(d_lane));
+    // fl(1 / (2r+1)^2) in a scalar register (as a literal it cannot be an operand of a packed multiply, and the
+    // two slots would be scaled by two instructions)
+    float rcp_full_s = 1.0f / (float)(WIN * WIN);
+    asm volatile("" : "+s"(rcp_full_s));
     uint32_t large_lane[2];
     bool xd_valid[2];
     unsigned roff[2];  // byte offset of the right census word inside its row
@@ -191,9 +206,10 @@ __device__ __forceinline__ void pair_disparity_pass(
             load_right(i + RPF, rq[RPF - 1]);
             const double mG[2] = {cur.mG[0], cur.mG[1]};
             const float inv_f[2] = {cur.inv_f[0], cur.inv_f[1]};
-            f2 gp[RG + 1];  // guide of the output row at tile columns 2(l + u), 2(l + u) + 1
+            f2 gq[RG + 1];  // guide of the output row at tile columns 2(l - u), 2(l - u) + 1  (lanes l < u read the
+                            // floats in front of the row: their terms leave the wavefront with the shifts)
 #pragma unroll
-            for (int u = 0; u <= RG; ++u) gp[u] = goutg[k * (TC / 2) + u];
+            for (int u = 0; u <= RG; ++u) gq[u] = goutg[k * (TC / 2) - u];
             // 2a. the row leaving the window [i - 2r, i] retires first, so that its ring registers are
             //     free before the new row's values are formed (no register copies at the loop edge)
             if (STEADY || i >= WIN) {
@@ -304,46 +320,45 @@ __device__ __forceinline__ void pair_disparity_pass(
                 if (STEADY || i >= 2 * HALO) {
                     // 6. sums over the 2r + 1 stage-1 columns starting in each slot.  Both columns of a lane are
                     //    evaluated at ONE reference guide value c = G(2l): E = A c + B in float64, and the window sum
-                    //    of A_j G(x) + B_j is  sum E_j + sum A_j (G(x) - c_j)  with c_j the reference of column j's lane.
+                    //    of A_j G(x) + B_j is  sum_j [E_j + A_j (G(x) - c_j)]  with c_j the reference of column j's lane.
                     //    Every term is small where the guide is locally smooth and every difference is between guide
-                    //    values a few columns apart, so float32 lane chains suffice; and because a lane's two columns
-                    //    share their reference, the correction needs one product per LANE of the window (with the
-                    //    pair sum A_even + A_odd) instead of one per column.
+                    //    values a few columns apart, so float32 suffices; and because a lane's two columns share
+                    //    their reference, a lane contributes ONE term  (E_even + E_odd) + (A_even + A_odd)(G(x) - c)
+                    //    to an output whose window holds both of its columns.
+                    //    The terms are formed in the lane that owns the columns (it reads the guide of the outputs
+                    //    to its left from the tile image) and travel down the lanes inside the shifted adds: lane m's
+                    //    term for the output u lanes to its left enters the chain at step u, so one chain of r
+                    //    shifted adds per slot sums values and corrections together.
+                    //    Slot 0 of lane l (x = 2l):     lanes l .. l+r-1 whole (its own lane without correction:
+                    //                                   G(x) = c), the even column of lane l+r.
+                    //    Slot 1 of lane l (x = 2l + 1): the odd column of lane l, lanes l+1 .. l+r whole.
                     const int o = i - 2 * HALO;
-                    f2 E, P[RG + 1];
-                    const double cref = (double)gp[0].x;
-                    E.x = (float)fma(A[0], cref, B[0]);
-                    E.y = (float)fma(A[1], cref, B[1]);
+                    const float c = gq[0].x;
+                    const double cref = (double)c;
+                    const float Ex = (float)fma(A[0], cref, B[0]);
+                    const float Ey = (float)fma(A[1], cref, B[1]);
                     const float a0 = (float)A[0], a1 = (float)A[1];
-                    P[0] = f2{a0, a0 + a1};    // (A of the lane's even column, A of the pair)
-                    float ee = E.x, eo = E.y, eer = E.x, eor = E.y;
+                    const float S = Ex + Ey;
+                    const f2 PA = f2{a0, a0 + a1}, PE = f2{Ex, S};   // (even column, whole lane)
+                    const f2 cc = f2{c, c};
+                    f2 sum = fma2(PA, gq[RG] - cc, PE);
 #pragma unroll
-                    for (int u = 1; u <= RG; ++u) {
-                        eer = ee; eor = eo;
-                        ee = E.x + dpp_f<DPP_WAVE_SHL1>(ee);
-                        eo = E.y + dpp_f<DPP_WAVE_SHL1>(eo);
-                        P[u].x = dpp_mov_f<DPP_WAVE_SHL1>(P[u - 1].x);
-                        P[u].y = dpp_mov_f<DPP_WAVE_SHL1>(P[u - 1].y);
+                    for (int u = RG - 1; u >= 1; --u) {
+                        const f2 X = fma2_hi(PA, gq[u] - cc, PE);
+                        sum.x = X.x + dpp_f<DPP_WAVE_SHL1>(sum.x);
+                        sum.y = X.y + dpp_f<DPP_WAVE_SHL1>(sum.y);
                     }
-                    f2 se;
-                    se.x = ee + eor;
-                    se.y = eo + dpp_f<DPP_WAVE_SHL1>(eer);
-                    // Slot 0 (x = 2l, G(x) = c of its own lane): lanes l+1 .. l+r-1 whole, the even column of lane l+r.
-                    // Slot 1 (x = 2l+1): its own column, lanes l+1 .. l+r whole.
-                    f2 dsum = f2{0.f, a1 * (gp[0].y - gp[0].x)};
-#pragma unroll
-                    for (int u = 1; u < RG; ++u) dsum = fma2(gp[0] - gp[u].xx, P[u].yy, dsum);
-                    dsum = fma2(gp[0] - gp[RG].xx, P[RG], dsum);
+                    sum.x = S + dpp_f<DPP_WAVE_SHL1>(sum.x);
+                    sum.y = fmaf(a1, gq[0].y - c, Ey) + dpp_f<DPP_WAVE_SHL1>(sum.y);
                     // 7. q and the running WTA.  a and b already carry the cost unit.  Full windows: one multiply by
                     //    fl(1 / (2r+1)^2), whose relative error is below 2^-25 for r = 1..4, so a window of equal
                     //    costs c (t32 = (2r+1)^2 c exactly) rounds to exactly c; clipped windows: one Newton step on
                     //    the reciprocal, exact whenever the quotient is representable.  Either way constant `large`
                     //    windows stay exact ties.
-                    const f2 t32 = se + dsum;
+                    const f2 t32 = sum;
                     f2 qv;
                     if (LEAN) {
-                        constexpr float rcp_full = 1.0f / (float)(WIN * WIN);
-                        qv = t32 * f2{rcp_full, rcp_full};
+                        qv = t32 * f2{rcp_full_s, rcp_full_s};
                     } else {
                         f2 areav, r0v;
                         if (INTERIOR) {
@@ -366,7 +381,7 @@ __device__ __forceinline__ void pair_disparity_pass(
                                 a.q_out[((size_t)d * H + yo) * W + pl.x[j]] = tf;
                         }
                         if (!LEAN) tf = (tf == tf) ? tf : __int_as_float(0x7f800000);
-                        const unsigned long long key = ((unsigned long long)ordered_bits(tf) << 32) | (uint32_t)d;
+                        const unsigned long long key = ((unsigned long long)ordered_bits(tf) << 32) | d_lane;
                         __hip_atomic_fetch_min(reinterpret_cast<LDS_AS unsigned long long *>(keyg + k * TC + j * 64), key,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
