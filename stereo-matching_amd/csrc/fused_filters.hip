@@ -25,7 +25,10 @@
 namespace shp {
 
 constexpr int FF_TW = 64, FF_TH = 16, FF_THREADS = 256, FF_ROWS_PER_THREAD = 4;
-constexpr int FF_MAX_RADIUS = 4;
+constexpr int FF_MAX_RADIUS = 8;
+#ifndef FF_BIL_UNROLL_MAX
+#define FF_BIL_UNROLL_MAX 2
+#endif
 
 struct FFArgs {
     const void *lw, *rw;
@@ -33,7 +36,7 @@ struct FFArgs {
     int H, W, d_begin, d_end;
     float kern[(2 * FF_MAX_RADIUS + 1) * (2 * FF_MAX_RADIUS + 1)];  // normalised spatial weights, row-major
     float kern1[2 * FF_MAX_RADIUS + 1];  // Gaussian: normalised 1-D weights
-    float denom;          // bilateral: -log2(e) / (2 sigma^2)
+    float vscale, inv_vscale;   // bilateral: sqrt(log2(e) / (2 sigma^2)) and its reciprocal
     uint32_t *mm;         // median: [d - d_begin][2] order-preserving (min, max) of the cost layer
     uint64_t *keys;
     int plain_median;     // test hook: take the plain bisection instead of the bit-sliced count
@@ -417,6 +420,7 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                 if (b == 255u) my255 = 1u; else myhi = max(myhi, b);
                 c = __uint_as_float(b);
             }
+            if (FILTER == STEREO_FILTER_BILATERAL) c *= a.vscale;
             if (idx < NP) cb[idx] = c;
         }
         if (MEDIAN) {
@@ -464,35 +468,63 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             }
         } else if (FILTER == STEREO_FILTER_BILATERAL) {
             // w = spatial * exp(-(v - c)^2 / (2 sigma^2))  (filters.py:299-304) evaluated as one hardware
-            // exp2 per window element: exp2((v - c)^2 * (-log2(e) / (2 sigma^2)) + log2(spatial)).  The
-            // weights agree with the reference's to a few float32 ulps, the filtered cost to ~1e-6.
+            // exp2 per window element: exp2(log2(spatial) - (v' - c')^2) on costs scaled by
+            // sqrt(log2(e) / (2 sigma^2)) when they were written to the tile (sum w v' / sum w is scaled back at
+            // the end): a subtract, a fused multiply-add and the exponential per element.  The weights agree
+            // with the reference's to a few float32 ulps, the filtered cost to ~1e-6.
             float c[FF_ROWS_PER_THREAD], wsum[FF_ROWS_PER_THREAD], vsum[FF_ROWS_PER_THREAD];
 #pragma unroll
             for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
                 c[j] = win[(j + RAD) * LW + RAD];
                 wsum[j] = 0.f; vsum[j] = 0.f;
             }
+            if (RAD <= FF_BIL_UNROLL_MAX) {
+                // a window row is read once for the (up to four) outputs it belongs to
 #pragma unroll
-            for (int rr = 0; rr < NR; ++rr) {
-                float v[K];
+                for (int rr = 0; rr < NR; ++rr) {
+                    float v[K];
 #pragma unroll
-                for (int dx = 0; dx < K; ++dx) v[dx] = win[rr * LW + dx];
+                    for (int dx = 0; dx < K; ++dx) v[dx] = win[rr * LW + dx];
 #pragma unroll
-                for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
-                    const int dy = rr - j;
-                    if (dy >= 0 && dy < K) {
+                    for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+                        const int dy = rr - j;
+                        if (dy >= 0 && dy < K) {
 #pragma unroll
-                        for (int dx = 0; dx < K; ++dx) {
-                            const float diff = v[dx] - c[j];
-                            const float w = __builtin_amdgcn_exp2f(fmaf(diff * diff, a.denom, a.kern[dy * K + dx]));
-                            wsum[j] += w;
-                            vsum[j] = fmaf(v[dx], w, vsum[j]);
+                            for (int dx = 0; dx < K; ++dx) {
+                                const float diff = v[dx] - c[j];
+                                const float w = __builtin_amdgcn_exp2f(fmaf(-diff, diff, a.kern[dy * K + dx]));
+                                wsum[j] += w;
+                                vsum[j] = fmaf(v[dx], w, vsum[j]);
+                            }
+                        }
+                    }
+                }
+            } else {
+                // large windows: the rows are a run-time loop (fully unrolled, four windows of up to 289 elements
+                // would not fit the instruction cache); same order of the sums as above
+#pragma unroll 1
+                for (int rr = 0; rr < NR; ++rr) {
+                    float v[K];
+#pragma unroll
+                    for (int dx = 0; dx < K; ++dx) v[dx] = win[rr * LW + dx];
+#pragma unroll
+                    for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
+                        const int dy = rr - j;
+                        if (dy >= 0 && dy < K) {
+                            const float *kr = a.kern + dy * K;
+#pragma unroll
+                            for (int dx = 0; dx < K; ++dx) {
+                                const float diff = v[dx] - c[j];
+                                const float w = __builtin_amdgcn_exp2f(fmaf(-diff, diff, kr[dx]));
+                                wsum[j] += w;
+                                vsum[j] = fmaf(v[dx], w, vsum[j]);
+                            }
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) outv[j] = (wsum[j] <= 0.f) ? c[j] : vsum[j] / wsum[j];
+            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) outv[j] = ((wsum[j] <= 0.f) ? c[j] : vsum[j] / wsum[j]) * a.inv_vscale;
         } else {
             // the bytes of this tile (halo included) lie in [tlo, thi]: so do all its medians.  Cost
             // layers mostly hold a narrow band of levels (plus 255 where a cost is `large`).
@@ -612,6 +644,10 @@ static int launch_ff_r(const FFArgs &a, int radius, hipStream_t s) {
         case 2: return launch_ff<FILTER, WORD64, 2>(a, s);
         case 3: return launch_ff<FILTER, WORD64, 3>(a, s);
         case 4: return launch_ff<FILTER, WORD64, 4>(a, s);
+        case 5: return launch_ff<FILTER, WORD64, 5>(a, s);
+        case 6: return launch_ff<FILTER, WORD64, 6>(a, s);
+        case 7: return launch_ff<FILTER, WORD64, 7>(a, s);
+        case 8: return launch_ff<FILTER, WORD64, 8>(a, s);
         default: set_error("fused filter kernels support radius 1..%d", FF_MAX_RADIUS); return STEREO_EUNSUPPORTED;
     }
 }
@@ -649,7 +685,8 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
             const int kk = (2 * radius + 1) * (2 * radius + 1);
             for (int i = 0; i < kk; ++i) a.kern[i] = (float)std::log2((double)a.kern[i]);
             const double denom = (double)(float)(2.0 * (sigma * sigma));   // the reference's float32 denominator
-            a.denom = (float)(-1.4426950408889634 / denom);
+            a.vscale = (float)std::sqrt(1.4426950408889634 / denom);
+            a.inv_vscale = (float)(1.0 / (double)a.vscale);
         }
     }
     switch (filter_kind) {

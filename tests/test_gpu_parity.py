@@ -448,13 +448,19 @@ def test_fused_guided_conditioning(oracle, scale):
     ("gaussian", {"gaussian_sigma": 1.0}, "FILTER_GAUSSIAN", 0, 1.0, 0.999),
     ("gaussian", {"gaussian_sigma": 0.6}, "FILTER_GAUSSIAN", 0, 0.6, 0.999),
     ("gaussian", {"gaussian_sigma": 1.3}, "FILTER_GAUSSIAN", 0, 1.3, 0.999),
-    ("gaussian", {"gaussian_sigma": 2.0}, "FILTER_GAUSSIAN", 0, 2.0, 0.999),      # radius 6: layer-at-a-time path
+    ("gaussian", {"gaussian_sigma": 2.0}, "FILTER_GAUSSIAN", 0, 2.0, 0.999),      # radius 6
+    ("gaussian", {"gaussian_sigma": 2.6}, "FILTER_GAUSSIAN", 0, 2.6, 0.999),      # radius 8: the largest fused one
+    ("gaussian", {"gaussian_sigma": 3.0}, "FILTER_GAUSSIAN", 0, 3.0, 0.999),      # radius 9: layer-at-a-time path
     ("bilateral", {"bilateral_sigma": 1.0}, "FILTER_BILATERAL", 0, 1.0, 0.95),
     ("bilateral", {"bilateral_sigma": 0.5}, "FILTER_BILATERAL", 0, 0.5, 0.95),
+    ("bilateral", {"bilateral_sigma": 2.0}, "FILTER_BILATERAL", 0, 2.0, 0.85),    # radius 6 (wider windows: more near-ties)
+    ("bilateral", {"bilateral_sigma": 3.0}, "FILTER_BILATERAL", 0, 3.0, 0.85),    # radius 9: layer-at-a-time path
     ("median", {"median_radius": 3}, "FILTER_MEDIAN_U8Q", 3, 0.0, 0.999),
     ("median", {"median_radius": 1}, "FILTER_MEDIAN_U8Q", 1, 0.0, 0.999),
     ("median", {"median_radius": 4}, "FILTER_MEDIAN_U8Q", 4, 0.0, 0.999),
-    ("median", {"median_radius": 6}, "FILTER_MEDIAN_U8Q", 6, 0.0, 0.999),          # layer-at-a-time path
+    ("median", {"median_radius": 6}, "FILTER_MEDIAN_U8Q", 6, 0.0, 0.999),
+    ("median", {"median_radius": 8}, "FILTER_MEDIAN_U8Q", 8, 0.0, 0.999),          # the largest fused one
+    ("median", {"median_radius": 9}, "FILTER_MEDIAN_U8Q", 9, 0.0, 0.999),          # layer-at-a-time path
 ])
 @pytest.mark.parametrize("h,w,dmax,wct", [(70, 150, 20, 4), (33, 130, 12, 8), (17, 64, 70, 4)])
 def test_compute_disparity_other_filters_vs_oracle(oracle, filt, kw, okind, oradius, oparam, min_agree, h, w, dmax, wct):
