@@ -393,37 +393,61 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
         if (tid < 3) { trange_buf[tid][0] = 255u; trange_buf[tid][1] = 0u; trange_buf[tid][2] = 0u; }
         __syncthreads();
     }
+    // median: the quantisation constants of 64 layers at a time, one layer per lane (two float64 divisions
+    // each), handed out per layer by a lane read
+    float lane_qlo = 0.f, lane_qscale = 0.f, lane_qinv = 0.f;
+    uint32_t lane_flags = 0u;   // bit 0: flat layer, bit 1: the layer's maximum is the census `large` value
     for (int d = a.d_begin; d < a.d_end; ++d) {
         float *cb = cbuf[(d - a.d_begin) & 1];
         // quantisation of this layer (filters.py:145-151,177-180)
         float qlo = 0.f, qscale = 0.f, qinv = 0.f;
-        bool flat = false;
+        bool flat = false, census_levels = false;
         if (MEDIAN) {
-            const uint32_t *m = a.mm + 2 * (size_t)(d - a.d_begin);
-            qlo = ordered_to_f32(m[0]);
-            const double dlo = (double)qlo, dhi = (double)ordered_to_f32(m[1]);
-            flat = dhi == dlo;
-            qscale = flat ? 0.f : (float)(255.0 / (dhi - dlo));
-            qinv = flat ? 0.f : (float)((dhi - dlo) / 255.0);
+            const int dl = (d - a.d_begin) & 63;
+            if (dl == 0) {
+                const int dd = min(d + (tid & 63), a.d_end - 1);
+                const uint32_t *m = a.mm + 2 * (size_t)(dd - a.d_begin);
+                lane_qlo = ordered_to_f32(m[0]);
+                const float fhi = ordered_to_f32(m[1]);
+                const double dlo = (double)lane_qlo, dhi = (double)fhi;
+                const bool fl = dhi == dlo;
+                lane_qscale = fl ? 0.f : (float)(255.0 / (dhi - dlo));
+                lane_qinv = fl ? 0.f : (float)((dhi - dlo) / 255.0);
+                lane_flags = (fl ? 1u : 0u) | ((fhi == a.cfg.large && lane_qlo >= 0.f && a.cfg.large > 0.f) ? 2u : 0u);
+            }
+            qlo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_qlo), dl));
+            qscale = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_qscale), dl));
+            qinv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_qinv), dl));
+            const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)lane_flags, dl);
+            flat = (fl & 1u) != 0u;
+            // A census cost that is not `large` is at most a tenth of it (census.py:240), so in a layer whose
+            // maximum is `large` and whose minimum is not negative every byte is 0 .. 26 or 255: the bit-sliced
+            // median needs no range of the tile's bytes, and the bookkeeping for it is skipped.
+            census_levels = BITSLICED && (fl & 2u) != 0u && !flat && !a.plain_median;
         }
         uint32_t *trange = trange_buf[(d - a.d_begin) % 3];
         uint32_t mylo = 255u, myhi = 0u, my255 = 0u;
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const int idx = tid + j * FF_THREADS;
+            // the last slot holds the few pixels beyond a multiple of the workgroup size: wavefronts whose
+            // lanes all lie beyond the tile skip it
+            if (j == PT - 1 && (tid & ~63) + j * FF_THREADS >= NP) continue;
             float c = ff_cost<WordT>(rw, a.cfg, lword[j], lvalid[j], ro[j], gxs[j], d);
             if (MEDIAN) {
                 float s = (c - qlo) * qscale;
                 s = fminf(fmaxf(s, 0.f), 255.f);
                 const uint32_t b = flat ? 0u : (uint32_t)rintf(s);
-                mylo = min(mylo, b);   // (a thread's surplus slot repeats a tile pixel)
-                if (b == 255u) my255 = 1u; else myhi = max(myhi, b);
+                if (!census_levels) {
+                    mylo = min(mylo, b);   // (a thread's surplus slot repeats a tile pixel)
+                    if (b == 255u) my255 = 1u; else myhi = max(myhi, b);
+                }
                 c = __uint_as_float(b);
             }
             if (FILTER == STEREO_FILTER_BILATERAL) c *= a.vscale;
             if (idx < NP) cb[idx] = c;
         }
-        if (MEDIAN) {
+        if (MEDIAN && !census_levels) {
             // one LDS atomic triple per wavefront: (255 - min), max and the 255 flag travel through the lanes in one word
             uint32_t nlo = 255u - mylo;
 #pragma unroll
@@ -528,7 +552,9 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
         } else {
             // the bytes of this tile (halo included) lie in [tlo, thi]: so do all its medians.  Cost
             // layers mostly hold a narrow band of levels (plus 255 where a cost is `large`).
-            const int tlo = (int)trange[0], thi2 = max((int)trange[1], tlo), has255 = (int)trange[2];
+            const int tlo = census_levels ? 0 : (int)trange[0];
+            const int thi2 = census_levels ? 26 : max((int)trange[1], tlo);
+            const int has255 = census_levels ? 1 : (int)trange[2];
             const int thi = has255 ? 255 : thi2;
             int med[FF_ROWS_PER_THREAD];
             if (BITSLICED && thi2 - tlo <= 30 && !a.plain_median) {
