@@ -262,6 +262,10 @@ static bool fused_path_applies(const StereoParams *p) {
     if (p->filter_kind == STEREO_FILTER_GUIDED) return fused_guided_supported(p->guided_radius);
     if (p->filter_kind == STEREO_FILTER_GAUSSIAN) return fused_filter_supported(p->filter_kind, radius_from_sigma(p->gaussian_sigma));
     if (p->filter_kind == STEREO_FILTER_BILATERAL) return fused_filter_supported(p->filter_kind, radius_from_sigma(p->bilateral_sigma));
+    if (p->filter_kind == STEREO_FILTER_MEDIAN) {   // the exact median is fused for exactly summable census weights only
+        CensusCfg cfg;
+        if (make_census_cfg(p->wct_radius, p->base_weight, &cfg) != STEREO_OK || !cfg.exact) return false;
+    }
     return fused_filter_supported(p->filter_kind, p->median_radius);
 }
 

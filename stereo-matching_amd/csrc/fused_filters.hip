@@ -40,6 +40,7 @@ struct FFArgs {
     uint32_t *mm;         // median: [d - d_begin][2] order-preserving (min, max) of the cost layer
     uint64_t *keys;
     int plain_median;     // test hook: take the plain bisection instead of the bit-sliced count
+    uint32_t code_large;  // exact median: code of an invalid pixel = largest valid cost in units + 1
 };
 
 __device__ __forceinline__ int ff_reflect101(int i, int n) {
@@ -60,6 +61,18 @@ __device__ __forceinline__ float ff_cost(const WordT *__restrict__ rw, const Cen
     const WordT rword = rw[ro + (ok ? xr : gx)];
     const float c = pair_cost<WordT>(lword, rword, cfg);
     return ok ? c : cfg.large;
+}
+
+// Exact median (scipy / vectorized / naive methods) of exactly summable census costs: the cost of a pixel in
+// integer units, or `code_large` (one above every valid cost) where the reference writes `large`.  The map from
+// codes to float32 costs is strictly increasing, so the median code is the code of the median cost.
+template <typename WordT>
+__device__ __forceinline__ uint32_t ff_code(const WordT *__restrict__ rw, const CensusCfg &cfg, WordT lword, bool lvalid,
+                                            int ro, int gx, int d, uint32_t code_large) {
+    const int xr = gx - d;
+    const bool ok = lvalid && xr >= cfg.radius;
+    const WordT rword = rw[ro + (ok ? xr : gx)];
+    return ok ? field_sum((WordT)(lword ^ rword)) : code_large;
 }
 
 // ---- pass 1 (median only): min / max of every cost layer ---------------------------------------
@@ -353,6 +366,7 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
     constexpr int PT = (NP + FF_THREADS - 1) / FF_THREADS;   // halo pixels per thread
     constexpr int NR = FF_ROWS_PER_THREAD + K - 1;           // tile rows one thread's four windows span
     constexpr bool MEDIAN = FILTER == STEREO_FILTER_MEDIAN_U8Q;
+    constexpr bool MEDX = FILTER == STEREO_FILTER_MEDIAN;     // exact median on integer cost codes
     __shared__ float cbuf[2][NP];
     // median: min / max byte of the cost tiles of disparities d, d + 1, d + 2 (slot = index mod 3); a slot is
     // reset two iterations before it is used, after the barrier that ends its last readers
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
         const int idx = min(tid + j * FF_THREADS, NP - 1);
         const int ly = idx / LW, lx = idx - ly * LW;
         int gy = y0 - RAD + ly, gx = x0 - RAD + lx;
-        if (MEDIAN) { gy = min(max(gy, 0), H - 1); gx = min(max(gx, 0), W - 1); }   // replicate (cv2.medianBlur)
+        if (MEDIAN || MEDX) { gy = min(max(gy, 0), H - 1); gx = min(max(gx, 0), W - 1); }   // replicate (cv2.medianBlur, scipy mode="nearest")
         else { gy = ff_reflect101(gy, H); gx = ff_reflect101(gx, W); }               // reflect-101
         ro[j] = gy * W;
         gxs[j] = gx;
@@ -389,8 +403,8 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
 #pragma unroll
     for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) best[j] = SHP_KEY_INIT;
 
-    if (MEDIAN) {
-        if (tid < 3) { trange_buf[tid][0] = 255u; trange_buf[tid][1] = 0u; trange_buf[tid][2] = 0u; }
+    if (MEDIAN || MEDX) {
+        if (tid < 3) { trange_buf[tid][0] = MEDX ? 0xffffffffu : 255u; trange_buf[tid][1] = 0u; trange_buf[tid][2] = 0u; }
         __syncthreads();
     }
     // median: the quantisation constants of 64 layers at a time, one layer per lane (two float64 divisions
@@ -426,13 +440,20 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             census_levels = BITSLICED && (fl & 2u) != 0u && !flat && !a.plain_median;
         }
         uint32_t *trange = trange_buf[(d - a.d_begin) % 3];
-        uint32_t mylo = 255u, myhi = 0u, my255 = 0u;
+        uint32_t mylo = MEDX ? 2047u : 255u, myhi = 0u, my255 = 0u;
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const int idx = tid + j * FF_THREADS;
             // the last slot holds the few pixels beyond a multiple of the workgroup size: wavefronts whose
             // lanes all lie beyond the tile skip it
             if (j == PT - 1 && (tid & ~63) + j * FF_THREADS >= NP) continue;
+            if (MEDX) {
+                const uint32_t e = ff_code<WordT>(rw, a.cfg, lword[j], lvalid[j], ro[j], gxs[j], d, a.code_large);
+                mylo = min(mylo, e);   // (a thread's surplus slot repeats a tile pixel)
+                myhi = max(myhi, e);
+                if (idx < NP) cb[idx] = __uint_as_float(e);
+                continue;
+            }
             float c = ff_cost<WordT>(rw, a.cfg, lword[j], lvalid[j], ro[j], gxs[j], d);
             if (MEDIAN) {
                 float s = (c - qlo) * qscale;
@@ -463,10 +484,24 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                 if (my255) atomicOr(&trange[2], 1u);
             }
         }
+        if (MEDX) {
+            // range of the tile's codes: (2047 - min) and max travel through the lanes in one word
+            uint32_t nlo = 2047u - mylo;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)((nlo << 11) | myhi), off, 64);
+                nlo = max(nlo, other >> 11);
+                myhi = max(myhi, other & 2047u);
+            }
+            if ((tid & 63) == 0) {
+                atomicMin(&trange[0], 2047u - nlo);
+                atomicMax(&trange[1], myhi);
+            }
+        }
         __syncthreads();
-        if (MEDIAN && tid == 0) {
+        if ((MEDIAN || MEDX) && tid == 0) {
             uint32_t *later = trange_buf[(d - a.d_begin + 2) % 3];
-            later[0] = 255u; later[1] = 0u; later[2] = 0u;
+            later[0] = MEDX ? 0xffffffffu : 255u; later[1] = 0u; later[2] = 0u;
         }
 
         float outv[FF_ROWS_PER_THREAD];
@@ -490,6 +525,15 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                 for (int dy = 0; dy < K; ++dy) o = fmaf(hrow[j + dy], a.kern1[dy], o);
                 outv[j] = o;
             }
+        } else if (MEDX) {
+            const int tlo = (int)trange[0], thi = max((int)trange[1], tlo);
+            int med[FF_ROWS_PER_THREAD];
+            if (thi - tlo < 32) median_bisect<K, 6, LW>(win, tlo, thi, med);
+            else if (thi - tlo < 128) median_bisect<K, 8, LW>(win, tlo, thi, med);
+            else median_bisect<K, 12, LW>(win, tlo, thi, med);
+#pragma unroll
+            for (int j = 0; j < FF_ROWS_PER_THREAD; ++j)
+                outv[j] = (uint32_t)med[j] == a.code_large ? a.cfg.large : (float)med[j] * a.cfg.unit;
         } else if (FILTER == STEREO_FILTER_BILATERAL) {
             // w = spatial * exp(-(v - c)^2 / (2 sigma^2))  (filters.py:299-304) evaluated as one hardware
             // exp2 per window element: exp2(log2(spatial) - (v' - c')^2) on costs scaled by
@@ -650,8 +694,10 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
 }
 
 bool fused_filter_supported(int filter_kind, int radius) {
+    // (the exact median in addition needs exactly summable census weights: launch_fused_filter refuses the others)
     return (filter_kind == STEREO_FILTER_MEDIAN_U8Q || filter_kind == STEREO_FILTER_GAUSSIAN ||
-            filter_kind == STEREO_FILTER_BILATERAL) && radius >= 1 && radius <= FF_MAX_RADIUS;
+            filter_kind == STEREO_FILTER_BILATERAL || filter_kind == STEREO_FILTER_MEDIAN) &&
+           radius >= 1 && radius <= FF_MAX_RADIUS;
 }
 
 size_t fused_filter_minmax_bytes(int n_disp) { return (size_t)n_disp * 8; }
@@ -694,6 +740,12 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
     memset(&a, 0, sizeof(a));
     a.lw = d_lw; a.rw = d_rw; a.cfg = cfg; a.H = H; a.W = W; a.d_begin = d_begin; a.d_end = d_end;
     a.mm = d_mm; a.keys = d_keys; a.plain_median = plain_median ? 1 : 0;
+    if (filter_kind == STEREO_FILTER_MEDIAN) {
+        if (!(cfg.exact && cfg.unit > 0.f)) { set_error("the fused exact median needs exactly summable census weights"); return STEREO_EUNSUPPORTED; }
+        // largest valid cost in units: all 8 directions x all rings set = 8 * (2^field_bits - 1)
+        a.code_large = (cfg.word64 ? 8u * 255u : 8u * 15u) + 1u;
+        return launch_ff_w<STEREO_FILTER_MEDIAN>(a, radius, s);
+    }
     if (filter_kind != STEREO_FILTER_MEDIAN_U8Q) {
         gaussian_kernel_host(radius, sigma, a.kern);
         if (filter_kind == STEREO_FILTER_GAUSSIAN) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random small problems through the public compute_disparity against the oracle pipeline
 (guided radii 1-5 and eps from 1e-5 to 0.5, both census word sizes, every filter, odd shapes, dmax
-above the width, disparity sub-ranges).  Test infrastructure: `python tests/fuzz_vs_oracle.py N SEED`
+above the width, disparity sub-ranges; seeds from 1000 on draw filter radii up to 9 and the exact median).  Test infrastructure: `python tests/fuzz_vs_oracle.py N SEED`
 prints one line per failing case (exit status 1 if any failed); tests/test_gpu_fuzz.py runs a fixed
 batch of cases."""
 import os
@@ -50,6 +50,26 @@ def run_cases(n_cases: int, seed: int, verbose: bool = True, only=None, override
         else:
             oparam = float(rng.choice([0.4, 0.7, 1.0, 1.3]))
             okind, oradius, kw = orc.FILTER_BILATERAL, 0, {"bilateral_sigma": oparam}
+        if seed >= 1000:
+            # wide batches: filter radii up to 9 (8 is the largest volume-free one), the exact median, guided
+            # radii up to 9.  Drawn from a second generator so that the pinned batches keep their sequence.
+            rng2 = np.random.default_rng(seed * 7919 + case)
+            if filt == "guided":
+                oradius = int(rng2.choice([1, 3, 5, 6, 7, 8, 9]))
+                kw = {"guided_radius": oradius, "guided_eps": oparam}
+            elif filt == "median":
+                oradius = int(rng2.integers(1, 10))
+                if rng2.random() < 0.6:
+                    okind = orc.FILTER_MEDIAN
+                    kw = {"median_radius": oradius, "median_method": str(rng2.choice(["scipy", "vectorized", "naive"]))}
+                else:
+                    kw = {"median_radius": oradius}
+            elif filt == "gaussian":
+                oparam = float(rng2.choice([0.5, 1.0, 1.5, 1.9, 2.3, 2.6, 3.0]))
+                kw = {"gaussian_sigma": oparam}
+            else:
+                oparam = float(rng2.choice([0.5, 1.0, 1.5, 2.0, 2.6, 3.0]))
+                kw = {"bilateral_sigma": oparam}
         if filt in ("gaussian", "bilateral"):
             # the oracle's reflect padding needs the pad to be shorter than the image side
             r = max(int(np.ceil(3 * oparam)), 1)

@@ -4,7 +4,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [11, 12, 101, 102])   # seeds >= 100 also vary the base weight and feed uint8 images
+# seeds >= 100 also vary the base weight and feed uint8 images; seeds >= 1000 draw filter radii up to 9 (guided,
+# median, Gaussian, bilateral) and the exact median
+@pytest.mark.parametrize("seed", [11, 12, 101, 102, 1001, 1002])
 def test_random_small_cases_match_oracle(oracle, seed, capsys):
     import fuzz_vs_oracle
 

@@ -461,6 +461,15 @@ def test_fused_guided_conditioning(oracle, scale):
     ("median", {"median_radius": 6}, "FILTER_MEDIAN_U8Q", 6, 0.0, 0.999),
     ("median", {"median_radius": 8}, "FILTER_MEDIAN_U8Q", 8, 0.0, 0.999),          # the largest fused one
     ("median", {"median_radius": 9}, "FILTER_MEDIAN_U8Q", 9, 0.0, 0.999),          # layer-at-a-time path
+    # exact float32 median (scipy / vectorized / naive): fused on integer cost codes, bit-exact
+    ("median", {"median_radius": 1, "median_method": "scipy"}, "FILTER_MEDIAN", 1, 0.0, 1.0),
+    ("median", {"median_radius": 3, "median_method": "vectorized"}, "FILTER_MEDIAN", 3, 0.0, 1.0),
+    ("median", {"median_radius": 4, "median_method": "naive"}, "FILTER_MEDIAN", 4, 0.0, 1.0),
+    ("median", {"median_radius": 6, "median_method": "scipy"}, "FILTER_MEDIAN", 6, 0.0, 1.0),
+    ("median", {"median_radius": 8, "median_method": "scipy"}, "FILTER_MEDIAN", 8, 0.0, 1.0),
+    ("median", {"median_radius": 9, "median_method": "scipy"}, "FILTER_MEDIAN", 9, 0.0, 1.0),   # layer-at-a-time path
+    # weights that are not exactly summable: the exact median stays on the layer-at-a-time path
+    ("median", {"median_radius": 3, "median_method": "scipy", "base_weight": 3.3}, "FILTER_MEDIAN", 3, 0.0, 1.0),
 ])
 @pytest.mark.parametrize("h,w,dmax,wct", [(70, 150, 20, 4), (33, 130, 12, 8), (17, 64, 70, 4)])
 def test_compute_disparity_other_filters_vs_oracle(oracle, filt, kw, okind, oradius, oparam, min_agree, h, w, dmax, wct):
@@ -470,7 +479,7 @@ def test_compute_disparity_other_filters_vs_oracle(oracle, filt, kw, okind, orad
     import stereo
     from synth import synth_pair_gray
     left, right, _ = synth_pair_gray(h, w, dmax, seed=h + w)
-    dsi = oracle.wct_cost_volume(left, right, dmax, radius=wct)
+    dsi = oracle.wct_cost_volume(left, right, dmax, radius=wct, base_weight=kw.get("base_weight", 8.0))
     kind = getattr(oracle, okind)
     dref, cref, layers = oracle.aggregate_and_wta(dsi, left, kind, oradius, oparam, want_layers=True)
     d, c = stereo.compute_disparity(left, right, dmax, wct_radius=wct, filter_type=filt, show_progress=False, **kw)
