@@ -22,6 +22,13 @@ def main() -> None:
         hits = glob.glob(os.path.join(src, trace, "**", "*kernel_stats.csv"), recursive=True)
         if hits:
             shutil.copy(hits[0], os.path.join(dst, out))
+    for name in ("param_table.txt",):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+    for f in ("bilateral", "median"):   # counter passes of the 8K filters, when tools/pmc_passes.sh was run for them
+        hit = os.path.join(src, f"pmc_{f}", "pmc_per_launch.json")
+        if os.path.exists(hit):
+            shutil.copy(hit, os.path.join(dst, "config5", f"{f}_pmc_per_launch.json"))
     print("collected into", dst)
 
 
