@@ -20,6 +20,8 @@ struct FastArgs {
     int n_slices;           // gridDim.z; slice z handles every n_slices-th chunk of the range
     int radius;             // census radius
     float unit;             // value of one cost unit
+    int unit_pow2;          // the cost unit is a power of two (two-column kernel: it then goes into the final scale factor)
+    float lean_scale;       // two-column kernel: factor from a full window's sum to the filtered cost
     uint32_t large_units;   // `large` in cost units
     int atomic_out;
     // Tail split (two-column kernel): workgroups from index split_first on are slices of tiles -- tile

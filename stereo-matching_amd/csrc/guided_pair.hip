@@ -14,6 +14,7 @@
 // Workgroups are 8 wavefronts (the per-lane state is twice as large), each marching down the
 // tile rows for one disparity at a time.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -81,13 +82,17 @@ struct PairLane {
 template <int RG, bool WORD64, int TH, bool QOUT, int MODE>
 __device__ __forceinline__ void pair_disparity_pass(
     const FastArgs &a, const PairLds<typename std::conditional<WORD64, uint64_t, uint32_t>::type> &t, const int d,
-    const int lane, const int ty0, const PairLane &pl, const double inv_scale_d) {
+    const int lane, const int ty0, const PairLane &pl, const double inv_scale_d, const double inv_post) {
     constexpr int WIN = 2 * RG + 1;
     constexpr int HALO = 2 * RG;
     constexpr int NI = TH + 4 * RG;
     constexpr int TC = 128;
     constexpr bool INTERIOR = MODE >= 1;
     constexpr bool LEAN = MODE == 2;
+    // Tiles whose windows are all full stage the plain 1 / (var + eps) (see the kernel).  Their lean passes then
+    // work on a and b scaled by (2r+1)^2 / unit -- b' = sum(p) - a' mean(G) needs no product for its first
+    // term -- and scale the result once per output; their other passes multiply `inv_post` back in.
+    constexpr bool SCALED = LEAN && RG <= 3;
     using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
     const int H = a.H, W = a.W, R = a.radius;
     const WordT *rw = static_cast<const WordT *>(a.rw);
@@ -100,7 +105,12 @@ __device__ __forceinline__ void pair_disparity_pass(
     asm volatile("" : "+v"(d_lane));
     // fl(1 / (2r+1)^2) in a scalar register (as a literal it cannot be an operand of a packed multiply, and the
     // two slots would be scaled by two instructions)
-    float rcp_full_s = 1.0f / (float)(WIN * WIN);
+    // Scaled passes: the window sums are (2r+1)^4 / unit times the result.  fl(1 / (2r+1)^4) has a relative error
+    // below 2^-25 for r = 1..3, so a window of equal costs (the sum is (2r+1)^4 times the cost in units, exact)
+    // still gives exactly that cost; the cost unit, a power of two, goes into the same factor (with any other
+    // unit the kernel runs these tiles without lean passes).
+    // (the factor comes from the host as a kernel argument: a.lean_scale)
+    float rcp_full_s = a.lean_scale;
     asm volatile("" : "+s"(rcp_full_s));
     uint32_t large_lane[2];
     bool xd_valid[2];
@@ -260,11 +270,16 @@ __device__ __forceinline__ void pair_disparity_pass(
                 // 3. sums over the 2r + 1 columns ending in each slot: the box sums of column x - r
                 uint32_t e1 = C1[0], o1 = C1[1], e1r = C1[0], o1r = C1[1];
                 uint32_t cp = C1p, cpr = C1p;
-                int ei = I2[0], oi = I2[1], eir = I2[0], oir = I2[1];
-                float ef_ = F2.x, of_ = F2.y, efr = F2.x, ofr = F2.y;
+                // k p and g_lo p: with P = (even + odd column of a lane), the window ending in the odd column is
+                // P(l) + ... + P(l-r+1) + odd(l-r) and the one ending in the even column even(l) + P(l-1) + ... + P(l-r):
+                // one add for P and r shifted adds per slot (2r + 1 instead of 2r + 2 instructions)
+                const int Pi = I2[0] + I2[1];
+                const float Pf = F2.x + F2.y;
+                int ci = I2[1], di = Pi;
+                float cf = F2.y, df = Pf;
 #pragma unroll
                 for (int u = 0; u < RG; ++u) {
-                    e1r = e1; o1r = o1; eir = ei; oir = oi; efr = ef_; ofr = of_;   // partial sums of u + 1 lanes
+                    e1r = e1; o1r = o1;   // partial sums of u + 1 lanes
                     if (PACK16) {
                         cpr = cp;
                         cp = C1p + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)cp);
@@ -272,14 +287,16 @@ __device__ __forceinline__ void pair_disparity_pass(
                         e1 = C1[0] + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)e1);
                         o1 = C1[1] + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)o1);
                     }
-                    ei = I2[0] + dpp_i<DPP_WAVE_SHR1>(ei);
-                    oi = I2[1] + dpp_i<DPP_WAVE_SHR1>(oi);
-                    ef_ = F2.x + dpp_f<DPP_WAVE_SHR1>(ef_);
-                    of_ = F2.y + dpp_f<DPP_WAVE_SHR1>(of_);
+                    ci = Pi + dpp_i<DPP_WAVE_SHR1>(ci);
+                    cf = Pf + dpp_f<DPP_WAVE_SHR1>(cf);
+                    if (u + 1 < RG) {
+                        di = Pi + dpp_i<DPP_WAVE_SHR1>(di);
+                        df = Pf + dpp_f<DPP_WAVE_SHR1>(df);
+                    }
                 }
                 // (the integer partial sums are pinned: re-associated, each three-operand add would need its
                 //  lane-shifted operands as separate move instructions)
-                asm volatile("" : "+v"(e1), "+v"(o1), "+v"(ei), "+v"(oi), "+v"(cp));
+                asm volatile("" : "+v"(e1), "+v"(o1), "+v"(ci), "+v"(di), "+v"(cp));
                 uint32_t s1[2];
                 int si[2];
                 float sf[2];
@@ -291,10 +308,10 @@ __device__ __forceinline__ void pair_disparity_pass(
                     s1[0] = e1 + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)o1r);
                     s1[1] = o1 + e1r;
                 }
-                si[0] = ei + dpp_i<DPP_WAVE_SHR1>(oir);
-                sf[0] = ef_ + dpp_f<DPP_WAVE_SHR1>(ofr);
-                si[1] = oi + eir;
-                sf[1] = of_ + efr;
+                si[0] = I2[0] + dpp_i<DPP_WAVE_SHR1>(di);
+                sf[0] = F2.x + dpp_f<DPP_WAVE_SHR1>(df);
+                si[1] = ci;
+                sf[1] = cf;
                 // 4. a, b; 5. their vertical running sums over stage-1 rows [j - 2r, j]
                 const int k2 = (k + 1) % WIN;
                 if (STEADY || i >= HALO + WIN) {
@@ -310,8 +327,8 @@ __device__ __forceinline__ void pair_disparity_pass(
                                                      : pair_inv_n[clipped_len(ty0 - HALO + i - RG, RG, H)] * pl.invAX1[j];
                     const double s1d = (double)s1[j];
                     const double u = fma(-mG[j], s1d, fma((double)si[j], inv_scale_d, (double)sf[j]));
-                    const double av = u * (double)inv_f[j];
-                    const double bv = fma(-av, mG[j], s1d * ia);
+                    const double av = LEAN ? u * (double)inv_f[j] : u * (double)inv_f[j] * inv_post;
+                    const double bv = SCALED ? fma(-av, mG[j], s1d) : fma(-av, mG[j], s1d * ia);
                     A[j] += av;
                     B[j] += bv;
                     ar[j][k2] = av;
@@ -477,6 +494,13 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
 
     if (threadIdx.x == 0) { t.next_d[0] = 0; t.next_d[1] = 0x7fffffff; t.next_d[2] = 0; }
     __syncthreads();
+    // Tiles all of whose columns and rows (halo included) have full filter windows and valid census centres:
+    // their lean passes work on scaled a and b (pair_disparity_pass), so 1 / (var + eps) is staged as it is
+    // and the factor unit / (2r+1)^2 that the other tiles fold into it is applied by their other passes.
+    const bool lean_geometry = !QOUT && (ty0 - HALO >= a.radius) && (ty0 + TH + HALO <= H - a.radius) &&
+                               tx0 - HALO >= max(a.radius, 2 * RG) && tx0 - HALO + TC - 1 <= W - 1 - max(a.radius, 2 * RG);
+    const bool scaled_tile = lean_geometry && RG <= 3 && a.unit_pow2 != 0;
+    const double inv_post = scaled_tile ? (double)a.unit / (double)(WIN * WIN) : 1.0;
     bool finite_in = __float_as_uint(a.gmax[1]) == 0u;
     // Staging.  A workgroup owns its compute unit's whole LDS, so nothing else runs while the tile is
     // fetched: every global load of the tile is issued before the first result is used (one memory
@@ -530,7 +554,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
             const double mg = in ? m_in[u] : 0.0;
             t.mG[j * TC + deint(c)] = mg;
             const int cyy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1, cxx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
-            const float iv = in ? (float)(d_in[u] * (double)a.unit / (double)(cyy * cxx)) : 0.f;
+            const float iv = !in ? 0.f : scaled_tile ? (float)d_in[u] : (float)(d_in[u] * (double)a.unit / (double)(cyy * cxx));
             t.inv[j * TC + deint(c)] = iv;
             finite_in = finite_in && fabs(mg) <= 1.0e300 && fabsf(iv) <= 3.0e38f;
         }
@@ -563,7 +587,8 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
     // columns tx0 - 2r .. tx0 - 2r + 127: full filter windows, valid census centres, finite inputs
     const int xlo = tx0 - HALO, xhi = tx0 - HALO + TC - 1;
     const int xmargin = max(R, 2 * RG);
-    const bool lean_tile = !QOUT && interior && xlo >= xmargin && xhi <= W - 1 - xmargin && t.next_d[2] == 0;
+    const bool lean_tile = !QOUT && interior && xlo >= xmargin && xhi <= W - 1 - xmargin && t.next_d[2] == 0 &&
+                           (RG > 3 || a.unit_pow2 != 0);   // (= lean_geometry, finite inputs, and a unit the scaled passes can fold)
     const int n_disp = a.d_end - a.d_begin;
 
     for (;;) {
@@ -579,11 +604,11 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
             continue;
         }
         if (lean_tile && xlo - d >= R)
-            pair_disparity_pass<RG, WORD64, TH, QOUT, 2>(a, t, d, lane, ty0, pl, inv_scale_d);
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 2>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
         else if (interior)
-            pair_disparity_pass<RG, WORD64, TH, QOUT, 1>(a, t, d, lane, ty0, pl, inv_scale_d);
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 1>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
         else
-            pair_disparity_pass<RG, WORD64, TH, QOUT, 0>(a, t, d, lane, ty0, pl, inv_scale_d);
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 0>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
     }
     __syncthreads();
     const int skipped_d = t.next_d[1];
@@ -780,6 +805,12 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
     a.H = H; a.W = W; a.D = dmax; a.d_begin = d_begin; a.d_end = d_end;
     a.n_slices = n_slices < 1 ? 1 : n_slices;
     a.radius = cfg.radius; a.unit = cfg.unit;
+    {
+        int e;
+        a.unit_pow2 = std::frexp(cfg.unit, &e) == 0.5f ? 1 : 0;
+        const int rg = guided_radius, win = 2 * rg + 1;
+        a.lean_scale = rg <= 3 ? (1.0f / (float)(win * win * win * win)) * cfg.unit : 1.0f / (float)(win * win);
+    }
     a.large_units = (uint32_t)std::lround((double)cfg.large / (double)cfg.unit);
     a.atomic_out = a.n_slices > 1;
     a.gate_eps = gate_eps; a.gate_min = gate_min;

@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """Timing-only variants of the two-column fused kernel (wrong results on purpose): each removes one
 group of instructions from the row loop, so that the difference of the kernel times prices that group.
-Builds tools/ab/libstereo_ab_<name>.so; run `python bench.py --no-cpu-baseline` with STEREO_HIP_LIB set."""
+Builds tools/ab/libstereo_ab_<name>.so; run `python bench.py --no-cpu-baseline` with STEREO_HIP_LIB set.
+
+The edits are text replacements anchored on the kernel source as it was at commit 345c115 (the build whose
+prices DESIGN.md quotes): `git show 345c115:stereo-matching_amd/csrc/guided_pair.hip > /tmp/gp.hip` and point SRC
+at that copy to reproduce them.  Against a later source some anchors no longer exist and the script stops with
+the name of the first one; tools/ab/build_variant.sh builds variants of the current source from -D macros."""
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = os.path.join(ROOT, "stereo-matching_amd")
-SRC = os.path.join(PKG, "csrc", "guided_pair.hip")
+SRC = os.environ.get("AB_SRC", os.path.join(PKG, "csrc", "guided_pair.hip"))
 OUT = os.path.join(ROOT, "tools", "ab")
 
 KEEP = 'asm volatile("" :: "v"({0}));'
