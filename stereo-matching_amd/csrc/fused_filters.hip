@@ -36,6 +36,9 @@ struct FFArgs {
     int H, W, d_begin, d_end;
     float kern[(2 * FF_MAX_RADIUS + 1) * (2 * FF_MAX_RADIUS + 1)];  // normalised spatial weights, row-major
     float kern1[2 * FF_MAX_RADIUS + 1];  // Gaussian: normalised 1-D weights
+    // bilateral: log2 of the spatial weights, rows padded to an even length so that a pair of horizontally adjacent
+    // weights is one aligned 8-byte scalar load
+    alignas(8) float kernp[2 * FF_MAX_RADIUS + 1][2 * FF_MAX_RADIUS + 2];
     float vscale, inv_vscale;   // bilateral: sqrt(log2(e) / (2 sigma^2)) and its reciprocal
     uint32_t *mm;         // median: [d - d_begin][2] order-preserving (min, max) of the cost layer
     uint64_t *keys;
@@ -569,7 +572,13 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                 }
             } else {
                 // large windows: the rows are a run-time loop (fully unrolled, four windows of up to 289 elements
-                // would not fit the instruction cache); same order of the sums as above
+                // would not fit the instruction cache)
+                // Two horizontally adjacent elements of a window travel through packed instructions (difference,
+                // exponent, the two sums); an output's sums are kept as (even elements, odd elements) pairs.
+                typedef float fpair __attribute__((ext_vector_type(2)));
+                fpair ws2[FF_ROWS_PER_THREAD], vs2[FF_ROWS_PER_THREAD];
+#pragma unroll
+                for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) { ws2[j] = fpair{0.f, 0.f}; vs2[j] = fpair{0.f, 0.f}; }
 #pragma unroll 1
                 for (int rr = 0; rr < NR; ++rr) {
                     float v[K];
@@ -579,17 +588,28 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                     for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
                         const int dy = rr - j;
                         if (dy >= 0 && dy < K) {
-                            const float *kr = a.kern + dy * K;
+                            const float *kr = a.kernp[dy];
+                            const fpair cc = fpair{c[j], c[j]};
 #pragma unroll
-                            for (int dx = 0; dx < K; ++dx) {
-                                const float diff = v[dx] - c[j];
-                                const float w = __builtin_amdgcn_exp2f(fmaf(-diff, diff, kr[dx]));
-                                wsum[j] += w;
-                                vsum[j] = fmaf(v[dx], w, vsum[j]);
+                            for (int dx = 0; dx + 1 < K; dx += 2) {
+                                const fpair vv = fpair{v[dx], v[dx + 1]};
+                                const fpair diff = vv - cc;
+                                const fpair arg = __builtin_elementwise_fma(-diff, diff, fpair{kr[dx], kr[dx + 1]});
+                                const fpair w = fpair{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                                ws2[j] += w;
+                                vs2[j] = __builtin_elementwise_fma(vv, w, vs2[j]);
+                            }
+                            {   // K is odd: the last element of the row
+                                const float diff = v[K - 1] - c[j];
+                                const float w = __builtin_amdgcn_exp2f(fmaf(-diff, diff, kr[K - 1]));
+                                ws2[j].x += w;
+                                vs2[j].x = fmaf(v[K - 1], w, vs2[j].x);
                             }
                         }
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) { wsum[j] = ws2[j].x + ws2[j].y; vsum[j] = vs2[j].x + vs2[j].y; }
             }
 #pragma unroll
             for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) outv[j] = ((wsum[j] <= 0.f) ? c[j] : vsum[j] / wsum[j]) * a.inv_vscale;
@@ -762,6 +782,8 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
         if (filter_kind == STEREO_FILTER_BILATERAL) {
             const int kk = (2 * radius + 1) * (2 * radius + 1);
             for (int i = 0; i < kk; ++i) a.kern[i] = (float)std::log2((double)a.kern[i]);
+            for (int y = 0; y <= 2 * radius; ++y)
+                for (int x = 0; x <= 2 * radius; ++x) a.kernp[y][x] = a.kern[y * (2 * radius + 1) + x];
             const double denom = (double)(float)(2.0 * (sigma * sigma));   // the reference's float32 denominator
             a.vscale = (float)std::sqrt(1.4426950408889634 / denom);
             a.inv_vscale = (float)(1.0 / (double)a.vscale);
