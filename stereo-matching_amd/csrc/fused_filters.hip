@@ -347,8 +347,12 @@ __device__ __forceinline__ void median_bisect(const float *win, int tlo, int thi
 // instructions each): 7 masks of a column -> a 3-bit count per level held in three words; 7 such
 // columns -> a 6-bit count per level; the word of the predicate "count >= 25" has its lowest set bit at
 // the median level.  Column counts are shared through LDS by the seven windows that contain the column.
-__device__ __forceinline__ uint32_t bs_xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
-__device__ __forceinline__ uint32_t bs_maj3(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | (c & (a | b)); }
+// (written as the three-input logic instruction with its truth table: from the C expressions the compiler forms
+//  it for some of the adders only and spends two or three instructions on the others)
+__device__ __forceinline__ uint32_t bs_xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t bs_maj3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+__device__ __forceinline__ uint32_t bs_or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE); }
+__device__ __forceinline__ uint32_t bs_and3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x80); }
 // seven one-bit words -> their 3-bit sum (b0 + 2 b1 + 4 b2)
 __device__ __forceinline__ void bs_count7(const uint32_t *m, uint32_t &b0, uint32_t &b1, uint32_t &b2) {
     const uint32_t x1 = bs_xor3(m[0], m[1], m[2]), y1 = bs_maj3(m[0], m[1], m[2]);
@@ -624,12 +628,14 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             if (BITSLICED && thi2 - tlo <= 30 && !a.plain_median) {
                 // phase 1: 3-bit counts of the four 7-row column segments under this thread's outputs, for halo
                 // column lx; the six columns beyond 63 are taken by the first lanes of wavefront 0
-                auto column_counts = [&](int c, int qq) {
+                auto column_counts = [&](int c, int qq, auto census_tag) {
                     uint32_t m[NR];
 #pragma unroll
                     for (int rr = 0; rr < NR; ++rr) {
                         const uint32_t b = __float_as_uint(cb[(qq * FF_ROWS_PER_THREAD + rr) * LW + c]);
-                        m[rr] = 0xffffffffu << (b == 255u ? 31u : b - (uint32_t)tlo);
+                        // (census layers: bytes are 0 .. 26 or 255 and the tile's lowest level is 0)
+                        if (decltype(census_tag)::value) m[rr] = 0xffffffffu << min(b, 31u);
+                        else m[rr] = 0xffffffffu << (b == 255u ? 31u : b - (uint32_t)tlo);
                     }
 #pragma unroll
                     for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
@@ -641,8 +647,13 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                         colcnt[2 * FF_TH * BS_CW + o] = b2;
                     }
                 };
-                column_counts(lx, q);
-                if (tid < 4 * (LW - FF_TW)) column_counts(FF_TW + tid % (LW - FF_TW), tid / (LW - FF_TW));
+                if (census_levels) {
+                    column_counts(lx, q, std::true_type{});
+                    if (tid < 4 * (LW - FF_TW)) column_counts(FF_TW + tid % (LW - FF_TW), tid / (LW - FF_TW), std::true_type{});
+                } else {
+                    column_counts(lx, q, std::false_type{});
+                    if (tid < 4 * (LW - FF_TW)) column_counts(FF_TW + tid % (LW - FF_TW), tid / (LW - FF_TW), std::false_type{});
+                }
                 __syncthreads();
                 // phase 2: add the seven columns of each window, find the first level with count >= 25
 #pragma unroll
@@ -665,7 +676,7 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                     const uint32_t s3 = x8 ^ c4, c8 = x8 & c4;
                     const uint32_t s4 = bs_xor3(u[2][2], y8, c8), s5 = bs_maj3(u[2][2], y8, c8);
                     // S >= 25 = 16 + 8 + 1
-                    const uint32_t ge = s5 | (s4 & s3 & (s2 | s1 | s0));
+                    const uint32_t ge = s5 | bs_and3(s4, s3, bs_or3(s2, s1, s0));
                     const int t = __builtin_ctz(ge);   // bit 31 is always set: all 49 elements are <= level 31
                     med[j] = t == 31 ? (has255 ? 255 : tlo + 31) : tlo + t;
                 }
