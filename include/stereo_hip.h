@@ -209,8 +209,10 @@ int stereo_hip_release_cache(void);
 /* Test hook, no counterpart in the reference: selects the fused guided kernel compute_disparity
  * uses, so the variants can be compared on the same input.  0 = the best one that applies
  * (default), 1 = the general kernel (float64 sums exchanged through LDS), 2 = the fast kernel
- * with one image column per lane (the default fast kernel gives every lane two columns).  Mode 1
- * also makes the fused uint8-median kernel take its plain bisection instead of the bit-sliced count. */
+ * with one image column per lane (the default fast kernel gives every lane two columns), 3 = the
+ * two-column kernel with its second box stage in float64 (the default for eps between 2e-3 and 8e-3
+ * times max(1, max|guide|^2)).  Mode 1 also makes the fused uint8-median kernel take its plain
+ * bisection instead of the bit-sliced count. */
 int stereo_debug_force_general_kernel(int mode);
 
 /* Timing of the dominant (fused) kernel with HIP events recorded on the launch stream, for

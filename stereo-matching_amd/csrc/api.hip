@@ -148,6 +148,9 @@ struct FusedWs {
 // (8e-3: at 5e-3 two of 440 random frames were off by 1.1e-5 and 2.8e-5 of a cost unit where an overshoot next to a
 // run of `large` costs brings the filtered cost close to zero; from 6e-3 up the same frames are within 1e-6)
 constexpr double FAST_KERNEL_MIN_EPS = 8e-3;
+// ... and the two-column kernel with a float64 second stage from here on (below it the float32 sums of the
+// guide's low-order part in the FIRST stage limit the accuracy)
+constexpr double PRECISE_KERNEL_MIN_EPS = 2e-3;   // (1.8e-6 of a cost unit off the float64 kernel at 1e-3, half that here)
 constexpr int FUSED_MAX_DISPARITIES = 65536;  // per launch; sizes the per-layer min/max scratch of the median path
 static FusedWs fused_ws_layout(int H, int W, int wct_radius) {
     FusedWs w;
@@ -198,28 +201,46 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         // below this eps their rounding can exceed 1e-5 of a cost unit where the filtered cost is near zero.
         // Smaller eps takes the general kernel (float64 throughout, bit-identical to the CPU restatement).
         const bool eps_ok = p->guided_eps >= FAST_KERNEL_MIN_EPS || g_force_kernel == 2;
-        const bool pair = fused_pair_supported(cfg, p->guided_radius) && g_force_kernel == 0 && eps_ok;
-        const bool fast = fused_fast_supported(cfg, p->guided_radius) && g_force_kernel != 1 && eps_ok;
-        const int slices = pair ? fused_pair_slices(H, W, p->guided_radius, cfg.word64 != 0, d_end - d_begin)
+        const bool pair_cfg = fused_pair_supported(cfg, p->guided_radius) && (g_force_kernel == 0 || g_force_kernel == 3);
+        const bool pair = pair_cfg && g_force_kernel == 0 && eps_ok;
+        // the same kernel with a float64 second stage: eps from PRECISE_KERNEL_MIN_EPS up to the fast kernels' limit
+        const bool pair_precise = pair_cfg && (g_force_kernel == 3 || p->guided_eps >= PRECISE_KERNEL_MIN_EPS);
+        const bool fast = !pair_cfg && fused_fast_supported(cfg, p->guided_radius) && g_force_kernel != 1 && eps_ok;
+        const int slices = (pair || pair_precise) ? fused_pair_slices(H, W, p->guided_radius, cfg.word64 != 0, d_end - d_begin)
                            : fast ? fused_fast_slices(H, W, p->guided_radius, d_end - d_begin) : 1;
         if (slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
         const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();
         if (prof) SHP_HIP(hipEventRecord(g_prof.start[g_prof.used], s));
-        // eps is judged against the guide's range on the device (the range is only known there): a fast kernel
-        // runs iff eps >= FAST_KERNEL_MIN_EPS * max(1, max|guide|^2); the general kernel is enqueued behind it
-        // with the opposite test, so exactly one of the two does the frame and the call stays asynchronous.
-        // A forced kernel (test hook) runs unconditionally.
+        // eps is judged against the guide's range m = max(1, max|guide|^2) on the device (the range is only known
+        // there).  Every kernel that could serve the frame is enqueued with its own test -- the fast kernels run iff
+        // eps >= FAST_KERNEL_MIN_EPS * m, the precise two-column kernel iff PRECISE_KERNEL_MIN_EPS * m <= eps <
+        // FAST_KERNEL_MIN_EPS * m, the general kernel below that -- so exactly one does the frame (the others
+        // return at once) and the call stays asynchronous.  A forced kernel (test hook) runs unconditionally.
         const float gate_eps = (float)p->guided_eps;
         const float gate_min = g_force_kernel == 0 ? (float)FAST_KERNEL_MIN_EPS : 0.f;
-        int rc = pair ? launch_fused_guided_pair(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius,
-                                                 d_begin, d_end, slices, d_keys, d_q_out, s, progress, gate_eps, gate_min)
-                 : fast ? launch_fused_guided_fast(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius,
-                                                 d_begin, d_end, slices, d_keys, d_q_out, s, gate_eps, gate_min)
-                      : launch_fused_guided(lw, rw, &cfg, nullptr, d_left, STEREO_DT_F32, mean, invden, H, W, dmax,
-                                            p->guided_radius, d_begin, d_end, d_keys, d_q_out, 0, s);
-        if (rc == STEREO_OK && (pair || fast) && gate_min > 0.f)
+        const float gate_low = g_force_kernel == 0 ? (float)PRECISE_KERNEL_MIN_EPS : 0.f;
+        int rc = STEREO_OK;
+        bool gated = false;   // some kernel was enqueued with a test: the general kernel follows with the remaining range
+        if (pair) {
+            rc = launch_fused_guided_pair(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius, d_begin,
+                                          d_end, slices, d_keys, d_q_out, s, progress, gate_eps, gate_min);
+            gated = true;
+        }
+        if (rc == STEREO_OK && pair_precise) {
+            rc = launch_fused_guided_pair(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius, d_begin,
+                                          d_end, slices, d_keys, d_q_out, s, progress, gate_eps, gate_min, true, gate_low,
+                                          /*keys_prefilled=*/pair);
+            gated = true;
+        }
+        if (rc == STEREO_OK && fast) {
+            rc = launch_fused_guided_fast(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius, d_begin,
+                                          d_end, slices, d_keys, d_q_out, s, gate_eps, gate_min);
+            gated = true;
+        }
+        if (rc == STEREO_OK && !(gated && gate_min == 0.f))   // (a forced fast / precise kernel has done the frame)
             rc = launch_fused_guided(lw, rw, &cfg, nullptr, d_left, STEREO_DT_F32, mean, invden, H, W, dmax,
-                                     p->guided_radius, d_begin, d_end, d_keys, d_q_out, 0, s, gmax, gate_eps, gate_min);
+                                     p->guided_radius, d_begin, d_end, d_keys, d_q_out, 0, s, gated ? gmax : nullptr,
+                                     gate_eps, !gated ? 0.f : pair_precise ? gate_low : gate_min);
         if (prof) {
             SHP_HIP(hipEventRecord(g_prof.stop[g_prof.used], s));
             ++g_prof.used;
@@ -252,7 +273,7 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
 // progress while it runs; 0 when it does not (the flags are then set after the kernel).
 static int progress_tile_rows(const StereoParams *p, const CensusCfg &cfg) {
     if (p->filter_kind != STEREO_FILTER_GUIDED) return 0;
-    const bool eps_ok = p->guided_eps >= FAST_KERNEL_MIN_EPS;
+    const bool eps_ok = p->guided_eps >= PRECISE_KERNEL_MIN_EPS;   // (either variant of the two-column kernel)
     if (!(fused_pair_supported(cfg, p->guided_radius) && g_force_kernel == 0 && eps_ok)) return 0;
     return pair_tile_height(p->guided_radius, cfg.word64 != 0);
 }

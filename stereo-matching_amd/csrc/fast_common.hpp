@@ -38,6 +38,8 @@ struct FastArgs {
     // against the guide's range: the kernel runs iff eps >= gate_min * max(1, gmax^2) and leaves the
     // frame to the float64 kernel (launched behind it with the opposite test) otherwise.  0: no test.
     float gate_eps, gate_min;
+    float gate_low;         // two-column kernel, precise variant: lower end of its eps range (same scaling)
+    int precise;            // two-column kernel: float64 second stage
 };
 
 __device__ __forceinline__ bool eps_gate_takes_fast(float eps, float gate_min, float gmax) {

@@ -60,6 +60,14 @@ __device__ __forceinline__ f2 fma2_hi(f2 a, f2 b, f2 c) {
     return r;
 }
 
+// a float64 value of the lane CTRL away (both halves move; lanes without a source read zero)
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 // Tile column c inside a de-interleaved 128-column LDS row: even columns first, then odd ones.  Lane l
 // owns columns 2l and 2l + 1; with this order the lanes' accesses to either parity are consecutive
 // (no two-way bank conflict from the stride of two elements).
@@ -72,6 +80,7 @@ struct PairLane {
     bool x_valid[2];      // census centre valid in x
     double invAX1[2];     // cost unit / (columns of the clipped stage-1 window), 0 outside the image
     float cxf[2];         // columns of the clipped output window
+    double rcx[2];        // 1 / that (0 outside the image): the precise variant divides in float64
     int c1, c1b;          // de-interleaved positions of the stage-1 columns of slot 0 and slot 1 (clamped to >= 0)
 };
 
@@ -79,7 +88,9 @@ struct PairLane {
 // image and has a valid census centre, so the per-row tests vanish.  MODE 2: in addition every
 // column of the tile (halo included) has a valid match at this disparity and full filter
 // windows, and the tile's inputs are finite: no cost select, constant window area, no NaN test.
-template <int RG, bool WORD64, int TH, bool QOUT, int MODE>
+// PRECISE: the second box stage in float64 (lane shifts of both halves of every partial sum) instead of the
+// float32 terms: 22 % more vector instructions, no limit on eps from that stage.
+template <int RG, bool WORD64, int TH, bool QOUT, int MODE, bool PRECISE>
 __device__ __forceinline__ void pair_disparity_pass(
     const FastArgs &a, const PairLds<typename std::conditional<WORD64, uint64_t, uint32_t>::type> &t, const int d,
     const int lane, const int ty0, const PairLane &pl, const double inv_scale_d, const double inv_post) {
@@ -112,6 +123,7 @@ __device__ __forceinline__ void pair_disparity_pass(
     // (the factor comes from the host as a kernel argument: a.lean_scale)
     float rcp_full_s = a.lean_scale;
     asm volatile("" : "+s"(rcp_full_s));
+    const double lean_scale_d = SCALED ? (double)a.unit / (double)(WIN * WIN * WIN * WIN) : 1.0 / (double)(WIN * WIN);
     uint32_t large_lane[2];
     bool xd_valid[2];
     unsigned roff[2];  // byte offset of the right census word inside its row
@@ -350,6 +362,32 @@ __device__ __forceinline__ void pair_disparity_pass(
                     //                                   G(x) = c), the even column of lane l+r.
                     //    Slot 1 of lane l (x = 2l + 1): the odd column of lane l, lanes l+1 .. l+r whole.
                     const int o = i - 2 * HALO;
+                    f2 qv;
+                    if (PRECISE) {
+                        // the same windows on the float64 sums themselves: with P = (even + odd column of a lane),
+                        // slot 0 is P(l) + ... + P(l+r-1) + even(l+r) and slot 1 odd(l) + P(l+1) + ... + P(l+r)
+                        const double PAd = A[0] + A[1], PBd = B[0] + B[1];
+                        double cA = A[0], cB = B[0], dA = PAd, dB = PBd;
+#pragma unroll
+                        for (int u = 0; u < RG; ++u) {
+                            cA = PAd + dpp_d<DPP_WAVE_SHL1>(cA);
+                            cB = PBd + dpp_d<DPP_WAVE_SHL1>(cB);
+                            if (u + 1 < RG) {
+                                dA = PAd + dpp_d<DPP_WAVE_SHL1>(dA);
+                                dB = PBd + dpp_d<DPP_WAVE_SHL1>(dB);
+                            }
+                        }
+                        const double sA[2] = {cA, A[1] + dpp_d<DPP_WAVE_SHL1>(dA)};
+                        const double sB[2] = {cB, B[1] + dpp_d<DPP_WAVE_SHL1>(dB)};
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const double td = fma(sA[j], (double)gq[0][j], sB[j]);
+                            const double rs = LEAN ? lean_scale_d
+                                              : INTERIOR ? pair_inv_n[WIN] * pl.rcx[j]
+                                                         : pair_inv_n[clipped_len(ty0 + o, RG, H)] * pl.rcx[j];
+                            qv[j] = (float)(td * rs);
+                        }
+                    } else {
                     const float c = gq[0].x;
                     const double cref = (double)c;
                     const float Ex = (float)fma(A[0], cref, B[0]);
@@ -373,7 +411,6 @@ __device__ __forceinline__ void pair_disparity_pass(
                     //    the reciprocal, exact whenever the quotient is representable.  Either way constant `large`
                     //    windows stay exact ties.
                     const f2 t32 = sum;
-                    f2 qv;
                     if (LEAN) {
                         qv = t32 * f2{rcp_full_s, rcp_full_s};
                     } else {
@@ -387,6 +424,7 @@ __device__ __forceinline__ void pair_disparity_pass(
                         }
                         const f2 q0 = t32 * r0v;
                         qv = fma2(fma2(-q0, areav, t32), r0v, q0);
+                    }
                     }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -441,7 +479,7 @@ __host__ __device__ inline TilePos pair_tile_of_index(int index, int nx, int ny,
     return p;
 }
 
-template <int RG, bool WORD64, int TH, int NW, bool QOUT>
+template <int RG, bool WORD64, int TH, int NW, bool QOUT, bool PRECISE>
 __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) {
     constexpr int WIN = 2 * RG + 1;
     constexpr int HALO = 2 * RG;
@@ -464,7 +502,12 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
     t.next_d = reinterpret_cast<int *>(sp); sp += 16;
     t.k = reinterpret_cast<short *>(sp);
 
-    if (a.gate_min > 0.f && !eps_gate_takes_fast(a.gate_eps, a.gate_min, *a.gmax)) return;
+    // eps against the guide's range: the float32 second stage serves eps >= gate_min * max(1, max|G|^2), the
+    // precise variant the range below it down to gate_low * max(1, max|G|^2) (the kernel that declines returns)
+    if (a.gate_min > 0.f) {
+        const bool fast_range = eps_gate_takes_fast(a.gate_eps, a.gate_min, *a.gmax);
+        if (PRECISE ? (fast_range || !eps_gate_takes_fast(a.gate_eps, a.gate_low, *a.gmax)) : !fast_range) return;
+    }
     const int lane = threadIdx.x & 63;
     const int H = a.H, W = a.W;
     const int nx = (a.W + TWV - 1) / TWV, ny = (a.H + TH - 1) / TH;
@@ -580,6 +623,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         pl.x_valid[j] = x_in && x >= R && x < W - R;
         pl.invAX1[j] = pair_inv_n[cx1] * (double)a.unit;
         pl.cxf[j] = (float)cx;
+        pl.rcx[j] = pair_inv_n[cx];
     }
     pl.c1 = deint(max(2 * lane - RG, 0));
     pl.c1b = deint(max(2 * lane - RG, 0) + 1);
@@ -604,11 +648,11 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
             continue;
         }
         if (lean_tile && xlo - d >= R)
-            pair_disparity_pass<RG, WORD64, TH, QOUT, 2>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 2, PRECISE>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
         else if (interior)
-            pair_disparity_pass<RG, WORD64, TH, QOUT, 1>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 1, PRECISE>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
         else
-            pair_disparity_pass<RG, WORD64, TH, QOUT, 0>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 0, PRECISE>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
     }
     __syncthreads();
     const int skipped_d = t.next_d[1];
@@ -673,13 +717,13 @@ struct PairTile {
 #define FP_NW 8
 #endif
 
-template <int RG, bool WORD64, bool QOUT>
+template <int RG, bool WORD64, bool QOUT, bool PRECISE>
 static int launch_pair_q(const FastArgs &a, hipStream_t s) {
     constexpr int TH = PairTile<RG, WORD64>::TH;
     static_assert(TH >= 2 * RG + 1, "tile too small");
     constexpr size_t smem = PairTile<RG, WORD64>::bytes(TH);
     static_assert(smem <= 160 * 1024, "tile image exceeds the LDS");
-    auto kern = fused_guided_pair_kernel<RG, WORD64, TH, FP_NW, QOUT>;
+    auto kern = fused_guided_pair_kernel<RG, WORD64, TH, FP_NW, QOUT, PRECISE>;
     SHP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
     const int tiles = ceil_div(a.W, 128 - 4 * RG) * ceil_div(a.H, TH);
@@ -691,7 +735,8 @@ static int launch_pair_q(const FastArgs &a, hipStream_t s) {
 
 template <int RG, bool WORD64>
 static int launch_pair_t(const FastArgs &a, hipStream_t s) {
-    return a.q_out ? launch_pair_q<RG, WORD64, true>(a, s) : launch_pair_q<RG, WORD64, false>(a, s);
+    if (a.precise) return a.q_out ? launch_pair_q<RG, WORD64, true, true>(a, s) : launch_pair_q<RG, WORD64, false, true>(a, s);
+    return a.q_out ? launch_pair_q<RG, WORD64, true, false>(a, s) : launch_pair_q<RG, WORD64, false, false>(a, s);
 }
 
 int pair_tile_height(int guided_radius, bool word64) {
@@ -796,7 +841,7 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
                              float *d_q_out, hipStream_t s, const BandProgress *progress, float gate_eps,
-                             float gate_min) {
+                             float gate_min, bool precise, float gate_low, bool keys_prefilled) {
     if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
     FastArgs a;
     memset(&a, 0, sizeof(a));
@@ -813,7 +858,7 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
     }
     a.large_units = (uint32_t)std::lround((double)cfg.large / (double)cfg.unit);
     a.atomic_out = a.n_slices > 1;
-    a.gate_eps = gate_eps; a.gate_min = gate_min;
+    a.gate_eps = gate_eps; a.gate_min = gate_min; a.gate_low = gate_low; a.precise = precise ? 1 : 0;
     if (progress && progress->band_tile_rows > 0) {
         a.progress = progress->words;
         a.band_tile_rows = progress->band_tile_rows;
@@ -841,7 +886,9 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
             if (last_plan.slices > 1) { a.split_first = last_plan.first; a.split_slices = last_plan.slices; }
         }
     }
-    if (a.split_slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
+    // (a second variant enqueued behind the first for the same frame -- only one of them runs -- must not wipe
+    //  what the first has written)
+    if (a.split_slices > 1 && !keys_prefilled) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
     switch (guided_radius) {
         case 1: return w64 ? launch_pair_t<1, true>(a, s) : launch_pair_t<1, false>(a, s);
         case 2: return w64 ? launch_pair_t<2, true>(a, s) : launch_pair_t<2, false>(a, s);

@@ -417,9 +417,30 @@ def test_fused_kernel_variants_agree(shape):
     d_gen, c_gen = _with_kernel(1, run)
     d_one, c_one = _with_kernel(2, run)
     d_two, c_two = _with_kernel(0, run)
-    for d, c in ((d_one, c_one), (d_two, c_two)):
+    d_pre, c_pre = _with_kernel(3, run)    # the two-column kernel with its second stage in float64
+    for d, c in ((d_one, c_one), (d_two, c_two), (d_pre, c_pre)):
         assert rel_err(c, c_gen) <= 1e-6
         assert np.mean(d == d_gen) >= 0.9995
+    assert rel_err(c_pre, c_gen) <= 2e-7
+
+
+@pytest.mark.parametrize("eps", [1e-3, 2e-3, 5e-3, 7.9e-3])   # (1e-3: the general kernel)
+@pytest.mark.parametrize("rg,wct", [(2, 4), (3, 4), (4, 4), (3, 8)])
+def test_guided_small_eps_takes_the_precise_kernel(oracle, eps, rg, wct):
+    """eps between 2e-3 and 8e-3 (for guides in [0, 1]): the two-column kernel with a float64 second stage, on a
+    frame with interior tiles, against the oracle; and the same frame through the general kernel."""
+    import stereo
+    from synth import synth_pair_gray
+    h, w, dmax = 140, 400, 30
+    left, right, _ = synth_pair_gray(h, w, dmax, seed=int(eps * 1e4) + rg)
+    dsi = oracle.wct_cost_volume(left, right, dmax, radius=wct)
+    dref, cref, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, rg, eps, want_layers=True)
+    run = lambda: stereo.compute_disparity(left, right, dmax, wct_radius=wct, guided_radius=rg, guided_eps=eps,
+                                           show_progress=False)
+    d, c = run()
+    assert_wta_matches(d, c, dref, cref, layers, min_agree=0.995)
+    d_gen, c_gen = _with_kernel(1, run)
+    assert rel_err(c, c_gen) <= 2e-6   # (the first stage's float32 sums of the guide's low-order part: ~2e-9 / eps)
 
 
 @pytest.mark.parametrize("scale", [1.0, 255.0, 1.0 / 255.0, 4096.0])
@@ -697,8 +718,8 @@ def test_guided_eps_is_judged_against_the_guide_range(oracle):
 @pytest.mark.parametrize("case,eps", [(1023, 0.005), (3681, 0.005), (3681, 0.0051), (1023, 0.0079), (3681, 0.008)])
 def test_guided_eps_near_the_kernel_choice(oracle, case, eps, capsys):
     """Two random frames on which the fast kernels were 1.1e-5 and 2.8e-5 of a cost unit off at eps = 0.005 (an
-    overshoot next to a run of `large` costs brings the filtered cost close to zero): eps below 8e-3 now takes the
-    float64 kernel; at and just above the limit the fast kernels stay within the bar."""
+    overshoot next to a run of `large` costs brings the filtered cost close to zero): eps below 8e-3 now takes a
+    kernel with a float64 second stage; at and just above the limit the fast kernels stay within the bar."""
     import fuzz_vs_oracle
 
     failures = fuzz_vs_oracle.run_cases(case + 1, 20261111, verbose=False, only={case}, override={"guided_eps": eps})
