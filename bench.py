@@ -67,6 +67,13 @@ def _pmc_summary(workload: str, library_version: str):
     return {k: v for k, v in summary.items() if isinstance(v, dict)}
 
 
+def _dominant_counters(summary):
+    """Counters of the dominant kernel: of the instances whose name matches (the variants of the kernel that
+    decline a frame return at once and appear with a few cycles), the one that was active longest."""
+    hits = [c for name, c in summary.items() if DOMINANT_KERNEL in name]
+    return max(hits, key=lambda c: c.get("GRBM_GUI_ACTIVE", 0.0)) if hits else None
+
+
 def measured_hbm_traffic(workload: str, library_version: str):
     """HBM bytes per launch of the dominant kernel from the committed counter summary: FETCH_SIZE and
     WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes read.  None when no summary of
@@ -74,12 +81,9 @@ def measured_hbm_traffic(workload: str, library_version: str):
     summary = _pmc_summary(workload, library_version)
     if summary is None:
         return None
-    try:
-        for name, counters in summary.items():
-            if DOMINANT_KERNEL in name and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-                return int((2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0)
-    except (OSError, ValueError):
-        pass
+    counters = _dominant_counters(summary)
+    if counters and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        return int((2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0)
     return None
 
 
@@ -90,15 +94,12 @@ def counter_ratios(workload: str, library_version: str):
     summary = _pmc_summary(workload, library_version)
     if summary is None:
         return None, None
-    try:
-        for name, c in summary.items():
-            if DOMINANT_KERNEL in name:
-                lds = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None
-                valu = (c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
-                        if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_ACTIVE_INST_VALU") else None)
-                return (round(lds, 4) if lds is not None else None, round(valu, 4) if valu is not None else None)
-    except (OSError, ValueError, KeyError):
-        pass
+    c = _dominant_counters(summary)
+    if c:
+        lds = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None
+        valu = (c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
+                if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_ACTIVE_INST_VALU") else None)
+        return (round(lds, 4) if lds is not None else None, round(valu, 4) if valu is not None else None)
     return None, None
 
 

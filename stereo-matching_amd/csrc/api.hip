@@ -212,24 +212,22 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();
         if (prof) SHP_HIP(hipEventRecord(g_prof.start[g_prof.used], s));
         // eps is judged against the guide's range m = max(1, max|guide|^2) on the device (the range is only known
-        // there).  Every kernel that could serve the frame is enqueued with its own test -- the fast kernels run iff
-        // eps >= FAST_KERNEL_MIN_EPS * m, the precise two-column kernel iff PRECISE_KERNEL_MIN_EPS * m <= eps <
-        // FAST_KERNEL_MIN_EPS * m, the general kernel below that -- so exactly one does the frame (the others
-        // return at once) and the call stays asynchronous.  A forced kernel (test hook) runs unconditionally.
+        // there).  Every kernel that could serve the frame is enqueued with its own test -- the fast variants run iff
+        // eps >= FAST_KERNEL_MIN_EPS * m, the precise variant of the two-column kernel (same launch) iff
+        // PRECISE_KERNEL_MIN_EPS * m <= eps < FAST_KERNEL_MIN_EPS * m, the general kernel below that -- so exactly
+        // one does the frame (the other returns at once) and the call stays asynchronous.  A forced kernel (test
+        // hook) runs unconditionally.
         const float gate_eps = (float)p->guided_eps;
         const float gate_min = g_force_kernel == 0 ? (float)FAST_KERNEL_MIN_EPS : 0.f;
         const float gate_low = g_force_kernel == 0 ? (float)PRECISE_KERNEL_MIN_EPS : 0.f;
         int rc = STEREO_OK;
         bool gated = false;   // some kernel was enqueued with a test: the general kernel follows with the remaining range
-        if (pair) {
+        if (pair || pair_precise) {
+            // one launch holds the fast and the precise variant of the two-column kernel; the test on the device
+            // picks one (or neither, when eps lies below the precise variant's range)
             rc = launch_fused_guided_pair(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius, d_begin,
-                                          d_end, slices, d_keys, d_q_out, s, progress, gate_eps, gate_min);
-            gated = true;
-        }
-        if (rc == STEREO_OK && pair_precise) {
-            rc = launch_fused_guided_pair(lw, rw, cfg, d_left, mean, invden, gmax, H, W, dmax, p->guided_radius, d_begin,
-                                          d_end, slices, d_keys, d_q_out, s, progress, gate_eps, gate_min, true, gate_low,
-                                          /*keys_prefilled=*/pair);
+                                          d_end, slices, d_keys, d_q_out, s, progress, gate_eps, gate_min, pair_precise,
+                                          gate_low);
             gated = true;
         }
         if (rc == STEREO_OK && fast) {

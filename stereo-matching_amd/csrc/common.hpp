@@ -150,8 +150,7 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
                              float *d_q_out, hipStream_t s, const BandProgress *progress = nullptr,
-                             float gate_eps = 0.f, float gate_min = 0.f, bool precise = false, float gate_low = 0.f,
-                             bool keys_prefilled = false);
+                             float gate_eps = 0.f, float gate_min = 0.f, bool precise = false, float gate_low = 0.f);
 int launch_progress_finish(uint32_t *words, int n_bands, uint32_t epoch, hipStream_t s);
 int launch_progress_wait(const uint32_t *words, int band, uint32_t epoch, hipStream_t s);
 bool fused_fast_supported(const CensusCfg &cfg, int guided_radius);

@@ -39,7 +39,8 @@ struct FastArgs {
     // frame to the float64 kernel (launched behind it with the opposite test) otherwise.  0: no test.
     float gate_eps, gate_min;
     float gate_low;         // two-column kernel, precise variant: lower end of its eps range (same scaling)
-    int precise;            // two-column kernel: float64 second stage
+    int precise;            // two-column kernel: with a test, the precise variant (float64 second stage) may take
+                            // the frame below the fast range; without one, it is the variant that runs
 };
 
 __device__ __forceinline__ bool eps_gate_takes_fast(float eps, float gate_min, float gmax) {

@@ -479,7 +479,7 @@ __host__ __device__ inline TilePos pair_tile_of_index(int index, int nx, int ny,
     return p;
 }
 
-template <int RG, bool WORD64, int TH, int NW, bool QOUT, bool PRECISE>
+template <int RG, bool WORD64, int TH, int NW, bool QOUT>
 __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) {
     constexpr int WIN = 2 * RG + 1;
     constexpr int HALO = 2 * RG;
@@ -504,9 +504,12 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
 
     // eps against the guide's range: the float32 second stage serves eps >= gate_min * max(1, max|G|^2), the
     // precise variant the range below it down to gate_low * max(1, max|G|^2) (the kernel that declines returns)
+    // (one launch holds both variants: a second launch that only declines would still start every workgroup)
+    bool precise = a.precise != 0;    // without a test (gate_min == 0): the variant the caller names
     if (a.gate_min > 0.f) {
         const bool fast_range = eps_gate_takes_fast(a.gate_eps, a.gate_min, *a.gmax);
-        if (PRECISE ? (fast_range || !eps_gate_takes_fast(a.gate_eps, a.gate_low, *a.gmax)) : !fast_range) return;
+        precise = !fast_range;
+        if (precise && !(a.precise != 0 && eps_gate_takes_fast(a.gate_eps, a.gate_low, *a.gmax))) return;
     }
     const int lane = threadIdx.x & 63;
     const int H = a.H, W = a.W;
@@ -647,12 +650,19 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
             atomicMin(&t.next_d[1], d);
             continue;
         }
-        if (lean_tile && xlo - d >= R)
-            pair_disparity_pass<RG, WORD64, TH, QOUT, 2, PRECISE>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
+        if (precise) {
+            if (lean_tile && xlo - d >= R)
+                pair_disparity_pass<RG, WORD64, TH, QOUT, 2, true>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
+            else if (interior)
+                pair_disparity_pass<RG, WORD64, TH, QOUT, 1, true>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
+            else
+                pair_disparity_pass<RG, WORD64, TH, QOUT, 0, true>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
+        } else if (lean_tile && xlo - d >= R)
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 2, false>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
         else if (interior)
-            pair_disparity_pass<RG, WORD64, TH, QOUT, 1, PRECISE>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 1, false>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
         else
-            pair_disparity_pass<RG, WORD64, TH, QOUT, 0, PRECISE>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
+            pair_disparity_pass<RG, WORD64, TH, QOUT, 0, false>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
     }
     __syncthreads();
     const int skipped_d = t.next_d[1];
@@ -717,13 +727,13 @@ struct PairTile {
 #define FP_NW 8
 #endif
 
-template <int RG, bool WORD64, bool QOUT, bool PRECISE>
+template <int RG, bool WORD64, bool QOUT>
 static int launch_pair_q(const FastArgs &a, hipStream_t s) {
     constexpr int TH = PairTile<RG, WORD64>::TH;
     static_assert(TH >= 2 * RG + 1, "tile too small");
     constexpr size_t smem = PairTile<RG, WORD64>::bytes(TH);
     static_assert(smem <= 160 * 1024, "tile image exceeds the LDS");
-    auto kern = fused_guided_pair_kernel<RG, WORD64, TH, FP_NW, QOUT, PRECISE>;
+    auto kern = fused_guided_pair_kernel<RG, WORD64, TH, FP_NW, QOUT>;
     SHP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
     const int tiles = ceil_div(a.W, 128 - 4 * RG) * ceil_div(a.H, TH);
@@ -735,8 +745,7 @@ static int launch_pair_q(const FastArgs &a, hipStream_t s) {
 
 template <int RG, bool WORD64>
 static int launch_pair_t(const FastArgs &a, hipStream_t s) {
-    if (a.precise) return a.q_out ? launch_pair_q<RG, WORD64, true, true>(a, s) : launch_pair_q<RG, WORD64, false, true>(a, s);
-    return a.q_out ? launch_pair_q<RG, WORD64, true, false>(a, s) : launch_pair_q<RG, WORD64, false, false>(a, s);
+    return a.q_out ? launch_pair_q<RG, WORD64, true>(a, s) : launch_pair_q<RG, WORD64, false>(a, s);
 }
 
 int pair_tile_height(int guided_radius, bool word64) {
@@ -841,7 +850,7 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
                              float *d_q_out, hipStream_t s, const BandProgress *progress, float gate_eps,
-                             float gate_min, bool precise, float gate_low, bool keys_prefilled) {
+                             float gate_min, bool precise, float gate_low) {
     if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
     FastArgs a;
     memset(&a, 0, sizeof(a));
@@ -886,9 +895,7 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
             if (last_plan.slices > 1) { a.split_first = last_plan.first; a.split_slices = last_plan.slices; }
         }
     }
-    // (a second variant enqueued behind the first for the same frame -- only one of them runs -- must not wipe
-    //  what the first has written)
-    if (a.split_slices > 1 && !keys_prefilled) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
+    if (a.split_slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
     switch (guided_radius) {
         case 1: return w64 ? launch_pair_t<1, true>(a, s) : launch_pair_t<1, false>(a, s);
         case 2: return w64 ? launch_pair_t<2, true>(a, s) : launch_pair_t<2, false>(a, s);

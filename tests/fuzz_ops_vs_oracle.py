@@ -62,7 +62,11 @@ def run_cases(n_cases: int, seed: int, verbose: bool = True) -> int:
                     r = int(rng.integers(0, 9))
                     tag += f" r {r}"
                     got, want = gf.box_filter_mean(img, r), orc.box_filter_mean(img, r)
-                    tol = 1e-11
+                    # A box mean is a difference of four table entries: both sides carry the rounding of entries as
+                    # large as the table's last one, divided by the window area (1 for r = 0, where nothing averages
+                    # it out).  The bar is that rounding, a few ulps of the largest entry, on top of 1e-11 relative.
+                    ulps = 2.0 * np.finfo(np.float64).eps * float(np.abs(orc.integral_image(img)).max())
+                    tol = 1e-11 + ulps / float(min(2 * r + 1, h) * min(2 * r + 1, w)) * 4.0
                 if exact and not np.array_equal(got, want):
                     problems.append(f"{op} of an integer-valued image differs")
                 elif rel_err(got, want) > tol:
