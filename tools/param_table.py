@@ -14,7 +14,8 @@ from synth import synth_pair_gray  # noqa: E402
 
 CASES = [
     ("guided r=3 eps=0.0154 (default)", dict(guided_eps=0.0154)),
-    ("guided r=3 eps=0.005 (below the fast kernels' eps limit)", dict(guided_eps=0.005)),
+    ("guided r=3 eps=0.005 (two-column kernel, float64 second stage)", dict(guided_eps=0.005)),
+    ("guided r=3 eps=0.001 (general float64 kernel)", dict(guided_eps=0.001)),
     ("guided r=1", dict(guided_radius=1, guided_eps=0.0154)),
     ("guided r=4", dict(guided_radius=4, guided_eps=0.0154)),
     ("guided r=6 (float64 fused kernel)", dict(guided_radius=6, guided_eps=0.0154)),
@@ -23,10 +24,12 @@ CASES = [
     ("base_weight 3.3 (weights not exactly summable), guided r=3", dict(base_weight=3.3, guided_eps=0.0154)),
     ("median r=3 opencv", dict(filter_type="median")),
     ("median r=3 scipy (exact float median)", dict(filter_type="median", median_method="scipy")),
-    ("median r=5 opencv (no fused kernel)", dict(filter_type="median", median_radius=5)),
+    ("median r=5 opencv", dict(filter_type="median", median_radius=5)),
     ("gaussian sigma=1", dict(filter_type="gaussian")),
-    ("gaussian sigma=2 (radius 6, no fused kernel)", dict(filter_type="gaussian", gaussian_sigma=2.0)),
+    ("gaussian sigma=2 (radius 6)", dict(filter_type="gaussian", gaussian_sigma=2.0)),
     ("bilateral sigma=1", dict(filter_type="bilateral")),
+    ("bilateral sigma=2 (radius 6)", dict(filter_type="bilateral", bilateral_sigma=2.0)),
+    ("median r=9 opencv (no fused kernel)", dict(filter_type="median", median_radius=9)),
 ]
 
 
