@@ -127,6 +127,9 @@ def parse_args():
                     help="fused: the volume-free kernel (default); two-call: cost volume written to HBM, then aggregated")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="rows of the workload the CPU baseline is timed on (0 = every row: the whole frame)")
+    ap.add_argument("--eps", type=float, default=0.0154,
+                    help="guided eps (the benchmark's is 0.0154; smaller values time the kernels that serve them: "
+                         "below 8e-3 the two-column kernel's precise variant, below 2e-3 the general kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true",
                     help="skip the second CPU figure (layers dealt to every core instead of the reference's threading)")
@@ -215,7 +218,10 @@ def main() -> None:
     if args.filter != "guided":
         desc += f", filter={args.filter}"
     params = _native.StereoParams(wct_radius=r_c, base_weight=8.0, filter_kind=getattr(_native, FILTERS[args.filter]), guided_radius=3,
-                                  guided_eps=0.0154, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
+                                  guided_eps=args.eps, median_radius=3, gaussian_sigma=1.0, bilateral_sigma=1.0)
+    if args.eps != 0.0154:
+        desc = desc.replace("eps=0.0154", f"eps={args.eps}")
+        args.no_cpu_baseline = True   # (the CPU leg is defined on the benchmark's own parameters)
     ws_bytes = ctypes.c_size_t(0)
     _native.check(lib.stereo_fused_workspace_bytes(H, W, params, ctypes.byref(ws_bytes)))
     workspace = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
