@@ -569,6 +569,23 @@ def test_full_size_strip_matches_oracle(oracle, motorcycle_pair):
     assert np.all(np.abs(cs[bad] - cref[bad]) <= TOL * np.maximum(1.0, np.abs(cref[bad])))
 
 
+def test_full_size_strip_small_eps_matches_oracle(oracle, motorcycle_pair):
+    """The same strip with eps = 0.005: the two-column kernel's variant with a float64 second stage."""
+    import stereo
+    left, right = motorcycle_pair
+    d, c = stereo.compute_disparity(left, right, 270, guided_eps=0.005, show_progress=False)
+    y0, y1, halo = 700, 760, 2 * 3 + 4
+    lo, hi = y0 - halo, y1 + halo
+    dref, cref = oracle.compute_disparity_allcores(np.ascontiguousarray(left[lo:hi]), np.ascontiguousarray(right[lo:hi]),
+                                                   270, wct_radius=4, radius=3, eps=0.005)
+    dref, cref = dref[halo:-halo], cref[halo:-halo]
+    ds, cs = d[y0:y1], c[y0:y1]
+    assert rel_err(cs, cref) <= TOL
+    assert np.mean(ds == dref) >= 0.999
+    bad = ds != dref
+    assert np.all(np.abs(cs[bad] - cref[bad]) <= TOL * np.maximum(1.0, np.abs(cref[bad])))
+
+
 def test_full_size_kernel_variants_and_shards(motorcycle_pair):
     """At the bench size: the three fused guided kernels agree, and disparity shards merged with the
     (cost, d) key minimum reproduce the unsharded frame bit for bit."""
