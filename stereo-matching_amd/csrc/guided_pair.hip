@@ -136,7 +136,9 @@ __device__ __forceinline__ void pair_disparity_pass(
 
     // 32-bit census words (radius <= 4): a cost is at most 1200 units, so the vertical sums (<= 8400) and the
     // window sums (<= 58800) of the two slots share one register, 16 bits each: half the adds and lane shifts.
-    constexpr bool PACK16 = !WORD64;
+    // 64-bit census words (radius <= 8): a valid cost is at most 2040 units, so passes without `large` costs (the
+    // lean ones) pack as well up to guided radius 3 ((r+1) lanes x (2r+1) rows x 2040 < 2^16).
+    constexpr bool PACK16 = !WORD64 || (LEAN && RG <= 3);
     uint32_t C1[2] = {0u, 0u};
     uint32_t C1p = 0u, prp[WIN];
     int I2[2] = {0, 0};
