@@ -129,7 +129,7 @@ def parse_args():
                     help="rows of the workload the CPU baseline is timed on (0 = every row: the whole frame)")
     ap.add_argument("--eps", type=float, default=0.0154,
                     help="guided eps (the benchmark's is 0.0154; smaller values time the kernels that serve them: "
-                         "below 8e-3 the two-column kernel's precise variant, below 2e-3 the general kernel)")
+                         "below 8e-3 the two-column kernel's precise variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true",
                     help="skip the second CPU figure (layers dealt to every core instead of the reference's threading)")

@@ -210,8 +210,8 @@ int stereo_hip_release_cache(void);
  * uses, so the variants can be compared on the same input.  0 = the best one that applies
  * (default), 1 = the general kernel (float64 sums exchanged through LDS), 2 = the fast kernel
  * with one image column per lane (the default fast kernel gives every lane two columns), 3 = the
- * two-column kernel with its second box stage in float64 (the default for eps between 2e-3 and 8e-3
- * times max(1, max|guide|^2)).  Mode 1 also makes the fused uint8-median kernel take its plain
+ * two-column kernel's precise variant, float64 where the fast one has float32 (the default for eps between 1e-4
+ * and 8e-3 times max(1, max|guide|^2)).  Mode 1 also makes the fused uint8-median kernel take its plain
  * bisection instead of the bit-sliced count. */
 int stereo_debug_force_general_kernel(int mode);
 

@@ -148,9 +148,9 @@ struct FusedWs {
 // (8e-3: at 5e-3 two of 440 random frames were off by 1.1e-5 and 2.8e-5 of a cost unit where an overshoot next to a
 // run of `large` costs brings the filtered cost close to zero; from 6e-3 up the same frames are within 1e-6)
 constexpr double FAST_KERNEL_MIN_EPS = 8e-3;
-// ... and the two-column kernel with a float64 second stage from here on (below it the float32 sums of the
-// guide's low-order part in the FIRST stage limit the accuracy)
-constexpr double PRECISE_KERNEL_MIN_EPS = 2e-3;   // (1.8e-6 of a cost unit off the float64 kernel at 1e-3, half that here)
+// ... and the precise variant of the two-column kernel (float64 sums of the guide's low-order part, float64 second
+// stage) from here on
+constexpr double PRECISE_KERNEL_MIN_EPS = 0.0;    // (every eps: the variant keeps nothing in float32 whose error grows as eps falls)
 constexpr int FUSED_MAX_DISPARITIES = 65536;  // per launch; sizes the per-layer min/max scratch of the median path
 static FusedWs fused_ws_layout(int H, int W, int wct_radius) {
     FusedWs w;
@@ -235,7 +235,10 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
                                           d_end, slices, d_keys, d_q_out, s, gate_eps, gate_min);
             gated = true;
         }
-        if (rc == STEREO_OK && !(gated && gate_min == 0.f))   // (a forced fast / precise kernel has done the frame)
+        // (a forced fast / precise kernel has done the frame; so has the two-column kernel when its precise
+        //  variant serves every eps the fast one declines)
+        const bool pair_serves_all = (pair || pair_precise) && pair_precise && PRECISE_KERNEL_MIN_EPS <= 0.0;
+        if (rc == STEREO_OK && !(gated && gate_min == 0.f) && !pair_serves_all)
             rc = launch_fused_guided(lw, rw, &cfg, nullptr, d_left, STEREO_DT_F32, mean, invden, H, W, dmax,
                                      p->guided_radius, d_begin, d_end, d_keys, d_q_out, 0, s, gated ? gmax : nullptr,
                                      gate_eps, !gated ? 0.f : pair_precise ? gate_low : gate_min);

@@ -88,8 +88,9 @@ struct PairLane {
 // image and has a valid census centre, so the per-row tests vanish.  MODE 2: in addition every
 // column of the tile (halo included) has a valid match at this disparity and full filter
 // windows, and the tile's inputs are finite: no cost select, constant window area, no NaN test.
-// PRECISE: the second box stage in float64 (lane shifts of both halves of every partial sum) instead of the
-// float32 terms: 22 % more vector instructions, no limit on eps from that stage.
+// PRECISE: float64 where the fast variant has float32 -- the sums of (guide's low-order part x cost) in the first
+// stage and the whole second box stage (lane shifts move both halves of every partial sum): 40 % more vector
+// instructions, no limit on eps.
 template <int RG, bool WORD64, int TH, bool QOUT, int MODE, bool PRECISE>
 __device__ __forceinline__ void pair_disparity_pass(
     const FastArgs &a, const PairLds<typename std::conditional<WORD64, uint64_t, uint32_t>::type> &t, const int d,
@@ -143,12 +144,14 @@ __device__ __forceinline__ void pair_disparity_pass(
     uint32_t C1p = 0u, prp[WIN];
     int I2[2] = {0, 0};
     f2 F2 = {0.f, 0.f};
+    double F2d[2] = {0.0, 0.0};   // PRECISE: the same sums (guide's low-order part times cost) in float64
     double A[2] = {0.0, 0.0}, B[2] = {0.0, 0.0};
     // rings of the rows inside the two vertical windows; a slot is first read one window length after it was
     // first written (the start-up row groups below are peeled and skip the retiring step), so none is cleared
     uint32_t pr[2][WIN];
     int kr[2][WIN];
     f2 gr[WIN];
+    double grd[2][WIN];
     double ar[2][WIN], br[2][WIN];
 
     auto row_of = [&](int i) -> int {
@@ -170,7 +173,7 @@ __device__ __forceinline__ void pair_disparity_pass(
     // Operands of a row are fetched one row ahead; the head of the next row is carried from one
     // row group into the next so that no group starts by waiting for its own loads.
     struct RowHead {
-        WordT L[2]; int k[2]; f2 glo; double mG[2]; float inv_f[2];
+        WordT L[2]; int k[2]; f2 glo; double mG[2]; float inv_f[2]; double inv_d[2];
     };
     RowHead cur;
     bool have_head = false;
@@ -195,6 +198,16 @@ __device__ __forceinline__ void pair_disparity_pass(
     };
 #pragma unroll
     for (int u = 0; u < RPF; ++u) load_right(u, rq[u]);
+    // PRECISE: 1 / (var + eps) in float64 from the statistics array itself (the tile image keeps it in float32),
+    // fetched with the other operands of a row, one row ahead
+    const __amdgpu_buffer_rsrc_t rsrc_inv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(a.invden), 0, (int)((size_t)H * W * sizeof(double)), 0x00020000);
+    unsigned ioff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tc1 = max(2 * lane - RG, 0) + j;   // tile column of the slot's stage-1 result
+        ioff[j] = (unsigned)min(max(pl.x[0] - 2 * lane + tc1, 0), W - 1) * (unsigned)sizeof(double);
+    }
     auto row_group = [&](const int base, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         LDS_AS const Pair<WordT> *Lg = lds_lane_ptr(reinterpret_cast<const Pair<WordT> *>(t.L + base * TC + 2 * lane));
@@ -216,7 +229,17 @@ __device__ __forceinline__ void pair_disparity_pass(
             r.k[0] = (int)(short)(kk & 0xffffu); r.k[1] = (int)kk >> 16;
             r.glo = gp;
             r.mG[0] = mGg0[k * TC]; r.mG[1] = mGg1[k * TC];
-            r.inv_f[0] = invg0[k * TC]; r.inv_f[1] = invg1[k * TC];
+            if (PRECISE) {
+                const int gy = min(max(ty0 - RG + base + k - HALO, 0), H - 1);
+                const int soff = gy * W * (int)sizeof(double);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc_inv, (int)ioff[j], soff, 0);
+                    r.inv_d[j] = __hiloint2double((int)v[1], (int)v[0]);
+                }
+            } else {
+                r.inv_f[0] = invg0[k * TC]; r.inv_f[1] = invg1[k * TC];
+            }
             return r;
         };
         if (!have_head) { cur = fetch_head(0); have_head = true; }
@@ -243,7 +266,8 @@ __device__ __forceinline__ void pair_disparity_pass(
                     I2[j] -= kr[j][k];
                 }
                 if (PACK16) C1p -= prp[k];
-                F2 -= gr[k];
+                if (PRECISE) { F2d[0] -= grd[0][k]; F2d[1] -= grd[1][k]; }
+                else F2 -= gr[k];
             }
             f2 pf;
             uint32_t pq[2];
@@ -275,7 +299,14 @@ __device__ __forceinline__ void pair_disparity_pass(
                 C1p += pp;
                 prp[k] = pp;
             }
-            {
+            if (PRECISE) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const double gl = (double)cur.glo[j] * (double)pq[j];   // (exact: 24 x 11 bits)
+                    F2d[j] += gl;
+                    grd[j][k] = gl;
+                }
+            } else {
                 const f2 gl = cur.glo * pf;
                 F2 += gl;
                 gr[k] = gl;
@@ -289,8 +320,10 @@ __device__ __forceinline__ void pair_disparity_pass(
                 // one add for P and r shifted adds per slot (2r + 1 instead of 2r + 2 instructions)
                 const int Pi = I2[0] + I2[1];
                 const float Pf = F2.x + F2.y;
+                const double Pd = F2d[0] + F2d[1];
                 int ci = I2[1], di = Pi;
                 float cf = F2.y, df = Pf;
+                double cd = F2d[1], dd = Pd;
 #pragma unroll
                 for (int u = 0; u < RG; ++u) {
                     e1r = e1; o1r = o1;   // partial sums of u + 1 lanes
@@ -302,10 +335,12 @@ __device__ __forceinline__ void pair_disparity_pass(
                         o1 = C1[1] + (uint32_t)dpp_i<DPP_WAVE_SHR1>((int)o1);
                     }
                     ci = Pi + dpp_i<DPP_WAVE_SHR1>(ci);
-                    cf = Pf + dpp_f<DPP_WAVE_SHR1>(cf);
+                    if (PRECISE) cd = Pd + dpp_d<DPP_WAVE_SHR1>(cd);
+                    else cf = Pf + dpp_f<DPP_WAVE_SHR1>(cf);
                     if (u + 1 < RG) {
                         di = Pi + dpp_i<DPP_WAVE_SHR1>(di);
-                        df = Pf + dpp_f<DPP_WAVE_SHR1>(df);
+                        if (PRECISE) dd = Pd + dpp_d<DPP_WAVE_SHR1>(dd);
+                        else df = Pf + dpp_f<DPP_WAVE_SHR1>(df);
                     }
                 }
                 // (the integer partial sums are pinned: re-associated, each three-operand add would need its
@@ -323,9 +358,17 @@ __device__ __forceinline__ void pair_disparity_pass(
                     s1[1] = o1 + e1r;
                 }
                 si[0] = I2[0] + dpp_i<DPP_WAVE_SHR1>(di);
-                sf[0] = F2.x + dpp_f<DPP_WAVE_SHR1>(df);
+                double sfd[2];
+                if (PRECISE) {
+                    sfd[0] = F2d[0] + dpp_d<DPP_WAVE_SHR1>(dd);
+                    sfd[1] = cd;
+                } else {
+                    sf[0] = F2.x + dpp_f<DPP_WAVE_SHR1>(df);
+                    sf[1] = cf;
+                    sfd[0] = (double)sf[0];
+                    sfd[1] = (double)sf[1];
+                }
                 si[1] = ci;
-                sf[1] = cf;
                 // 4. a, b; 5. their vertical running sums over stage-1 rows [j - 2r, j]
                 const int k2 = (k + 1) % WIN;
                 if (STEADY || i >= HALO + WIN) {
@@ -340,8 +383,9 @@ __device__ __forceinline__ void pair_disparity_pass(
                     const double ia = LEAN ? ia_full : INTERIOR ? ia_interior[j]
                                                      : pair_inv_n[clipped_len(ty0 - HALO + i - RG, RG, H)] * pl.invAX1[j];
                     const double s1d = (double)s1[j];
-                    const double u = fma(-mG[j], s1d, fma((double)si[j], inv_scale_d, (double)sf[j]));
-                    const double av = LEAN ? u * (double)inv_f[j] : u * (double)inv_f[j] * inv_post;
+                    const double u = fma(-mG[j], s1d, fma((double)si[j], inv_scale_d, sfd[j]));
+                    const double av = PRECISE ? (SCALED ? u * cur.inv_d[j] : u * cur.inv_d[j] * ia)
+                                      : LEAN  ? u * (double)inv_f[j] : u * (double)inv_f[j] * inv_post;
                     const double bv = SCALED ? fma(-av, mG[j], s1d) : fma(-av, mG[j], s1d * ia);
                     A[j] += av;
                     B[j] += bv;
