@@ -16,7 +16,7 @@ CASES = [
     ("guided r=3 eps=0.0154 (default)", dict(guided_eps=0.0154)),
     ("guided r=3 eps=0.005 (two-column kernel, precise variant)", dict(guided_eps=0.005)),
     ("guided r=3 eps=0.0001 (two-column kernel, precise variant)", dict(guided_eps=0.0001)),
-    ("guided r=1 eps=0.005 (general float64 kernel)", dict(guided_radius=1, guided_eps=0.005)),
+    ("guided r=1 eps=0.005 (precise variant)", dict(guided_radius=1, guided_eps=0.005)),
     ("guided r=1", dict(guided_radius=1, guided_eps=0.0154)),
     ("guided r=4", dict(guided_radius=4, guided_eps=0.0154)),
     ("guided r=6 (float64 fused kernel)", dict(guided_radius=6, guided_eps=0.0154)),
