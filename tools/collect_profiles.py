@@ -22,7 +22,7 @@ def main() -> None:
         hits = glob.glob(os.path.join(src, trace, "**", "*kernel_stats.csv"), recursive=True)
         if hits:
             shutil.copy(hits[0], os.path.join(dst, out))
-    for name in ("param_table.txt",):
+    for name in ("param_table.txt", "eps_0.005.json", "eps_0.0001.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, name))
     for f in ("bilateral", "median"):   # counter passes of the 8K filters, when tools/pmc_passes.sh was run for them
