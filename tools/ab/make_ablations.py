@@ -4,7 +4,7 @@ group of instructions from the row loop, so that the difference of the kernel ti
 Builds tools/ab/libstereo_ab_<name>.so; run `python bench.py --no-cpu-baseline` with STEREO_HIP_LIB set.
 
 The edits are text replacements anchored on the kernel source as it was at commit 345c115 (the build whose
-prices DESIGN.md quotes): `git show 345c115:stereo-matching_amd/csrc/guided_pair.hip > /tmp/gp.hip` and point SRC
+prices the design notes quote): `git show 345c115:stereo-matching_amd/csrc/guided_pair.hip > /tmp/gp.hip` and point SRC
 at that copy to reproduce them.  Against a later source some anchors no longer exist and the script stops with
 the name of the first one; tools/ab/build_variant.sh builds variants of the current source from -D macros."""
 import os

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which kernel serves which parameter set, and what a Motorcycle-sized compute_disparity call costs with it
-(2964 x 2000, dmax 270; host call, copies to and from the device included).  Feeds the table in INTEGRATION.md."""
+(2964 x 2000, dmax 270; host call, copies to and from the device included): one line per parameter set."""
 import os
 import sys
 import time
