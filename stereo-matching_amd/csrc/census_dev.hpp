@@ -6,12 +6,13 @@
 namespace shp {
 
 // Sum of the weighted direction fields of x, in units of cfg.unit.
-__device__ __forceinline__ uint32_t field_sum(uint32_t x) {
-    return __builtin_amdgcn_udot8(x, 0x11111111u, 0u, false);
+// `acc` is added by the dot instruction itself (its accumulator operand).
+__device__ __forceinline__ uint32_t field_sum(uint32_t x, uint32_t acc = 0u) {
+    return __builtin_amdgcn_udot8(x, 0x11111111u, acc, false);
 }
-__device__ __forceinline__ uint32_t field_sum(uint64_t x) {
+__device__ __forceinline__ uint32_t field_sum(uint64_t x, uint32_t acc = 0u) {
     uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    return __builtin_amdgcn_udot4(hi, 0x01010101u, __builtin_amdgcn_udot4(lo, 0x01010101u, 0u, false), false);
+    return __builtin_amdgcn_udot4(hi, 0x01010101u, __builtin_amdgcn_udot4(lo, 0x01010101u, acc, false), false);
 }
 
 // The reference's own evaluation order (census.py:198-201): float32 adds over

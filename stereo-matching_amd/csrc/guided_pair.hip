@@ -46,6 +46,9 @@ __constant__ double pair_inv_n[16] = {0.0,       1.0,       1.0 / 2.0,  1.0 / 3.
 __device__ __forceinline__ int clipped_len(int y, int r, int n) {
     return (y >= 0 && y < n) ? min(y + r, n - 1) - max(y - r, 0) + 1 : 0;
 }
+// A tile's key array holds (cost, d) as float64 patterns (see the end of pair_disparity_pass); the write-out turns
+// them into the library's ordered integer keys.  Start value: (+inf, d = 0), the pattern SHP_KEY_INIT maps to.
+#define PAIR_TILE_KEY_INIT (uint64_t(0x7F800000u) << 32)
 template <typename T>
 using Pair = T __attribute__((ext_vector_type(2)));  // the two slots of a lane, loaded with one LDS read
 // The float32 arithmetic of the two slots is written on pairs: with two wavefronts per SIMD every
@@ -113,8 +116,10 @@ __device__ __forceinline__ void pair_disparity_pass(
 
     // the disparity as the low half of every key of the pass: held in one vector register, so that a key is that
     // register and the one above it instead of a fresh copy of the scalar per key
-    uint32_t d_lane = (uint32_t)d;
-    asm volatile("" : "+v"(d_lane));
+    // (one such register per slot: with a shared one the second key's cost would first be copied above it)
+    uint32_t d_lane[2] = {(uint32_t)d, (uint32_t)d};
+    asm volatile("" : "+v"(d_lane[0]));
+    asm volatile("" : "+v"(d_lane[1]));
     // fl(1 / (2r+1)^2) in a scalar register (as a literal it cannot be an operand of a packed multiply, and the
     // two slots would be scaled by two instructions)
     // Scaled passes: the window sums are (2r+1)^4 / unit times the result.  fl(1 / (2r+1)^4) has a relative error
@@ -140,6 +145,11 @@ __device__ __forceinline__ void pair_disparity_pass(
     // 64-bit census words (radius <= 8): a valid cost is at most 2040 units, so passes without `large` costs (the
     // lean ones) pack as well up to guided radius 3 ((r+1) lanes x (2r+1) rows x 2040 < 2^16).
     constexpr bool PACK16 = !WORD64 || (LEAN && RG <= 3);
+#ifndef FP_NO_MAGIC
+    constexpr bool MAGIC = LEAN && PACK16 && !PRECISE;
+#else
+    constexpr bool MAGIC = false;
+#endif
     uint32_t C1[2] = {0u, 0u};
     uint32_t C1p = 0u, prp[WIN];
     int I2[2] = {0, 0};
@@ -274,7 +284,10 @@ __device__ __forceinline__ void pair_disparity_pass(
             // 1. costs in units; k*p and g_lo*p; 2b. the new row enters the vertical running sums
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const uint32_t fs = field_sum((WordT)(cur.L[j] ^ Rcur[j]));
+                // MAGIC: the cost is formed on top of the pattern of 2^23, so that the same register read as a float32
+                // is 2^23 + cost exactly (no integer-to-float conversion per slot: one packed subtraction for both);
+                // the 24-bit multiply and the 16-bit packing below read the low bits, which are the cost itself
+                const uint32_t fs = field_sum((WordT)(cur.L[j] ^ Rcur[j]), MAGIC ? 0x4B000000u : 0u);
                 uint32_t p;
                 if (LEAN) {
                     p = fs;
@@ -288,14 +301,15 @@ __device__ __forceinline__ void pair_disparity_pass(
                 }
                 int kp = __mul24(cur.k[j], (int)p);
                 asm volatile("" : "+v"(kp));  // one multiply: the running sum adds kp instead of re-deriving it
-                pf[j] = (float)p;
+                pf[j] = MAGIC ? __uint_as_float(p) : (float)p;
                 if (!PACK16) { C1[j] += p; pr[j][k] = p; }
                 I2[j] += kp;
                 kr[j][k] = kp;
                 pq[j] = p;
             }
+            if (MAGIC) pf -= f2{8388608.f, 8388608.f};
             if (PACK16) {
-                const uint32_t pp = pq[0] | (pq[1] << 16);
+                const uint32_t pp = MAGIC ? __builtin_amdgcn_perm(pq[1], pq[0], 0x05040100u) : (pq[0] | (pq[1] << 16));
                 C1p += pp;
                 prp[k] = pp;
             }
@@ -345,7 +359,9 @@ __device__ __forceinline__ void pair_disparity_pass(
                 }
                 // (the integer partial sums are pinned: re-associated, each three-operand add would need its
                 //  lane-shifted operands as separate move instructions)
-                asm volatile("" : "+v"(e1), "+v"(o1), "+v"(ci), "+v"(di), "+v"(cp));
+                //  (only the sums the variant uses: a pinned unused one costs a move of its zero per row)
+                if (PACK16) asm volatile("" : "+v"(ci), "+v"(di), "+v"(cp));
+                else asm volatile("" : "+v"(e1), "+v"(o1), "+v"(ci), "+v"(di));
                 uint32_t s1[2];
                 int si[2];
                 float sf[2];
@@ -458,7 +474,9 @@ __device__ __forceinline__ void pair_disparity_pass(
                     //    windows stay exact ties.
                     const f2 t32 = sum;
                     if (LEAN) {
-                        qv = t32 * f2{rcp_full_s, rcp_full_s};
+                        // (two plain multiplies: each result is the high word of its slot's key, see below)
+                        qv.x = t32.x * rcp_full_s;
+                        qv.y = t32.y * rcp_full_s;
                     } else {
                         f2 areav, r0v;
                         if (INTERIOR) {
@@ -482,8 +500,13 @@ __device__ __forceinline__ void pair_disparity_pass(
                                 a.q_out[((size_t)d * H + yo) * W + pl.x[j]] = tf;
                         }
                         if (!LEAN) tf = (tf == tf) ? tf : __int_as_float(0x7f800000);
-                        const unsigned long long key = ((unsigned long long)ordered_bits(tf) << 32) | d_lane;
-                        __hip_atomic_fetch_min(reinterpret_cast<LDS_AS unsigned long long *>(keyg + k * TC + j * 64), key,
+                        // The tile's keys are float64 patterns: high word = the cost's float32 pattern as it is, low
+                        // word = d.  The LDS unit's float64 minimum compares sign and magnitude, so the cost needs
+                        // no order-preserving integer map (two instructions per slot); the patterns are finite
+                        // float64 values for every float32 cost that is not NaN (a float32 infinity has the
+                        // exponent 0x7f8 of 0x7ff), and the low word breaks ties of equal costs.
+                        const double key = __hiloint2double(__float_as_int(tf), (int)d_lane[j]);
+                        __hip_atomic_fetch_min(reinterpret_cast<LDS_AS double *>(keyg + k * TC + j * 64), key,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
@@ -652,7 +675,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         }
     }
     if (!finite_in) t.next_d[2] = 1;  // (after the barrier below it reads 0 unless some thread saw a non-finite input)
-    for (int idx = threadIdx.x; idx < TH * TC; idx += NW * 64) t.key[idx] = SHP_KEY_INIT;
+    for (int idx = threadIdx.x; idx < TH * TC; idx += NW * 64) t.key[idx] = PAIR_TILE_KEY_INIT;
     if (threadIdx.x < 16) t.gout[TH * TC + threadIdx.x] = 0.f;
     __syncthreads();
 
@@ -717,7 +740,8 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         int o = idx / TC, c = idx % TC;
         int gy = ty0 + o, gx = tx0 - HALO + c;
         if (c >= HALO && c < TC - HALO && gy < H && gx < W) {
-            uint64_t key = t.key[o * TC + deint(c)];
+            const uint64_t tile_key = t.key[o * TC + deint(c)];
+            uint64_t key = make_key(__uint_as_float((uint32_t)(tile_key >> 32)), (uint32_t)tile_key);
             if (skipped_d != 0x7fffffff) {
                 const uint64_t kl = make_key(large_f, (uint32_t)skipped_d);
                 key = kl < key ? kl : key;

@@ -490,6 +490,35 @@ def test_cost_units_and_interior_tiles(oracle, base_weight, rg):
     assert np.all(np.abs(c[75:85, 200:250]) <= 1e-6) and np.all(np.abs(cref[75:85, 200:250]) <= 1e-6)
 
 
+@pytest.mark.parametrize("rg,wct", [(1, 4), (2, 4), (3, 4), (3, 8)])   # (radius 4: its running sums leave 1e-17, no ties)
+def test_exact_zero_cost_ties_take_the_lowest_disparity(rg, wct):
+    """A constant band in both images: whole windows of zero costs at every disparity, so the filtered costs tie at
+    exactly +0.0 and the lowest disparity has to win.  The two-column kernel keeps a tile's keys as float64 patterns
+    (cost pattern above d), which are denormal numbers for a zero cost: they must still be told apart by d.  The
+    general kernel (integer keys) is the comparison."""
+    import stereo
+    from synth import synth_pair_gray
+    h, w, dmax = 150, 420, 24
+    left, right, _ = synth_pair_gray(h, w, dmax, seed=5 + rg)
+    left[50:110, 130:320] = 0.5
+    right[50:110, 130:320] = 0.5
+    run = lambda: stereo.compute_disparity(left, right, dmax, wct_radius=wct, guided_radius=rg, guided_eps=0.0154,
+                                           show_progress=False)
+    d_two, c_two = _with_kernel(0, run)
+    d_gen, c_gen = _with_kernel(1, run)
+    band = (slice(75, 85), slice(200, 250))
+    assert np.all(c_two[band] == 0.0) and np.all(c_gen[band] == 0.0)
+    assert np.all(d_two[band] == 0) and np.all(d_gen[band] == 0)
+    # negative filtered costs (overshoot next to the band) keep their order too: a wrong order would show as a
+    # minimum that is not the general kernel's
+    assert (c_gen < 0).any()
+    assert rel_err(c_two, c_gen) <= 1e-6
+    # (around the band many layers lie within rounding of each other, so disparities are compared away from it)
+    away = np.ones((h, w), dtype=bool)
+    away[40:120, 100:350] = False
+    assert np.mean(d_two[away] == d_gen[away]) >= 0.999
+
+
 @pytest.mark.parametrize("filt,kw,okind,oradius,oparam,min_agree", [
     ("gaussian", {"gaussian_sigma": 1.0}, "FILTER_GAUSSIAN", 0, 1.0, 0.999),
     ("gaussian", {"gaussian_sigma": 0.6}, "FILTER_GAUSSIAN", 0, 0.6, 0.999),
