@@ -496,7 +496,7 @@ __device__ __forceinline__ void pair_disparity_pass(
                         if (QOUT) {
                             const int yo = ty0 + o;
                             const int tc = 2 * lane + j;
-                            if (tc >= HALO && tc < TC - HALO && pl.x[j] < W && yo < H)
+                            if (tc >= HALO && tc < TC - HALO && pl.x[j] >= 0 && pl.x[j] < W && yo < H)
                                 a.q_out[((size_t)d * H + yo) * W + pl.x[j]] = tf;
                         }
                         if (!LEAN) tf = (tf == tf) ? tf : __int_as_float(0x7f800000);
@@ -527,6 +527,18 @@ __device__ __forceinline__ void pair_disparity_pass(
 // the others idle; for the same reason the bottom row of tiles (clipped windows, the slower code variant)
 // starts the last band.
 struct TilePos { int x, y, band, band_rows; };
+// The tile columns cover nx * (tile width) >= W image columns.  The slack goes to the left edge -- the first tile
+// column starts this many columns left of the image -- because a tile skips every disparity beyond its rightmost
+// column: at the left edge the slack shortens the disparity loops of the first tile columns, at the right edge the
+// partly empty tile would cost as much as a full one.  Even, so that an image column keeps its slot in the lane.
+__host__ __device__ inline int pair_x_shift(int W, int tile_width) {
+#ifdef FP_NO_XSHIFT
+    return 0;
+#else
+    const int nx = (W + tile_width - 1) / tile_width;
+    return (nx * tile_width - W) & ~1;
+#endif
+}
 __host__ __device__ inline TilePos pair_tile_of_index(int index, int nx, int ny, int band_rows_max) {
     TilePos p;
     p.band = index / (band_rows_max * nx);
@@ -546,6 +558,18 @@ __host__ __device__ inline TilePos pair_tile_of_index(int index, int nx, int ny,
         }
     }
     return p;
+}
+
+// Start value of the keys of the tiles from index `first` on (one workgroup per tile): the tiles whose disparity
+// slices merge through atomicMin.
+__global__ __launch_bounds__(256) void pair_fill_split_keys_kernel(uint64_t *__restrict__ keys, int H, int W, int th,
+                                                                   int twv, int nx, int ny, int band_rows_max, int first) {
+    const TilePos tp = pair_tile_of_index(first + (int)blockIdx.x, nx, ny, band_rows_max);
+    const int x0 = tp.x * twv - pair_x_shift(W, twv), y0 = tp.y * th;
+    for (int i = threadIdx.x; i < th * twv; i += blockDim.x) {
+        const int y = y0 + i / twv, x = x0 + i % twv;
+        if (y < H && x >= 0 && x < W) keys[(size_t)y * W + x] = SHP_KEY_INIT;
+    }
 }
 
 template <int RG, bool WORD64, int TH, int NW, bool QOUT>
@@ -595,7 +619,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
     }
     const TilePos tp = pair_tile_of_index(tile_index, nx, ny, a.band_tile_rows > 0 ? a.band_tile_rows : ny);
     const int tile_x = tp.x, tile_y = tp.y, tile_band = tp.band, tile_band_rows = tp.band_rows;
-    const int tx0 = tile_x * TWV, ty0 = tile_y * TH;
+    const int tx0 = tile_x * TWV - pair_x_shift(W, TWV), ty0 = tile_y * TH;
     const WordT *lw = static_cast<const WordT *>(a.lw);
 
     const float gmax = *a.gmax;
@@ -739,7 +763,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
     for (int idx = threadIdx.x; idx < TH * TC; idx += NW * 64) {
         int o = idx / TC, c = idx % TC;
         int gy = ty0 + o, gx = tx0 - HALO + c;
-        if (c >= HALO && c < TC - HALO && gy < H && gx < W) {
+        if (c >= HALO && c < TC - HALO && gy < H && gx >= 0 && gx < W) {
             const uint64_t tile_key = t.key[o * TC + deint(c)];
             uint64_t key = make_key(__uint_as_float((uint32_t)(tile_key >> 32)), (uint32_t)tile_key);
             if (skipped_d != 0x7fffffff) {
@@ -864,7 +888,7 @@ static SplitPlan plan_tail_split(int W, int H, int th, int rg, int census_radius
     constexpr double STAGING = 1.0, BORDER = 1.12;
     auto cost = [&](int index, int slice, int n_slices) {
         const TilePos tp = pair_tile_of_index(index, nx, ny, band_rows_max);
-        const int tx0 = tp.x * twv, ty0 = tp.y * th;
+        const int tx0 = tp.x * twv - pair_x_shift(W, twv), ty0 = tp.y * th;
         const int lim = std::min(d_end, tx0 - halo + 127 - census_radius + 1);   // passes at d >= lim are skipped
         const int span = lim - d_begin - slice;
         const int passes = span > 0 ? ceil_div(span, n_slices) : 0;
@@ -965,7 +989,14 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
             if (last_plan.slices > 1) { a.split_first = last_plan.first; a.split_slices = last_plan.slices; }
         }
     }
-    if (a.split_slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
+    if (a.split_slices > 1) {
+        // only the split tiles merge their slices with atomicMin and need the start value; every other tile stores
+        const int th = pair_tile_height(guided_radius, w64), twv = 128 - 4 * guided_radius;
+        const int nx = ceil_div(W, twv), ny = ceil_div(H, th);
+        hipLaunchKernelGGL(pair_fill_split_keys_kernel, dim3(nx * ny - a.split_first), dim3(256), 0, s, d_keys, H, W, th,
+                           twv, nx, ny, a.band_tile_rows > 0 ? a.band_tile_rows : ny, a.split_first);
+        SHP_LAUNCH_CHECK();
+    }
     switch (guided_radius) {
         case 1: return w64 ? launch_pair_t<1, true>(a, s) : launch_pair_t<1, false>(a, s);
         case 2: return w64 ? launch_pair_t<2, true>(a, s) : launch_pair_t<2, false>(a, s);
