@@ -517,7 +517,11 @@ __device__ __forceinline__ void pair_disparity_pass(
     static_assert(2 * WIN >= 2 * HALO, "two peeled groups cover the start-up rows");
     row_group(0, std::false_type{});
     row_group(WIN, std::false_type{});
-    for (int base = 2 * WIN; base < NI; base += WIN) row_group(base, std::true_type{});
+    for (int base = 2 * WIN; base < NI; base += WIN) {
+        // (bottom tiles: a row group all of whose output rows lie below the image has nothing left to produce)
+        if (!INTERIOR && ty0 + base - 2 * HALO >= H) break;
+        row_group(base, std::true_type{});
+    }
 }
 
 // Tile order.  Workgroups start in the order of their index.  Rows are grouped in bands (the bands of the
