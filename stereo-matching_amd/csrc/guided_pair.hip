@@ -46,9 +46,14 @@ __constant__ double pair_inv_n[16] = {0.0,       1.0,       1.0 / 2.0,  1.0 / 3.
 __device__ __forceinline__ int clipped_len(int y, int r, int n) {
     return (y >= 0 && y < n) ? min(y + r, n - 1) - max(y - r, 0) + 1 : 0;
 }
-// A tile's key array holds (cost, d) as float64 patterns (see the end of pair_disparity_pass); the write-out turns
-// them into the library's ordered integer keys.  Start value: (+inf, d = 0), the pattern SHP_KEY_INIT maps to.
-#define PAIR_TILE_KEY_INIT (uint64_t(0x7F800000u) << 32)
+// A tile's key array holds (cost, d) as float64 patterns (see the end of pair_disparity_pass): high word = the
+// cost's float32 pattern, low word = (d << 7) xor the sign-extended top byte of that pattern.  The write-out turns
+// them into the library's ordered integer keys.  Start value: (+inf, d = 0), which SHP_KEY_INIT stands for.
+#define PAIR_TILE_KEY_INIT ((uint64_t(0x7F800000u) << 32) | uint64_t(0x7Fu))
+__device__ __forceinline__ uint64_t pair_tile_key_to_key(uint64_t tile_key) {
+    const uint32_t hi = (uint32_t)(tile_key >> 32), lo = (uint32_t)tile_key;
+    return make_key(__uint_as_float(hi), (lo ^ (uint32_t)((int32_t)hi >> 24)) >> 7);
+}
 template <typename T>
 using Pair = T __attribute__((ext_vector_type(2)));  // the two slots of a lane, loaded with one LDS read
 // The float32 arithmetic of the two slots is written on pairs: with two wavefronts per SIMD every
@@ -114,12 +119,8 @@ __device__ __forceinline__ void pair_disparity_pass(
     const int iv_lo = max(R - (ty0 - HALO), 0), iv_hi = min(H - R - (ty0 - HALO), NI);
     const int ii_lo = max(-(ty0 - HALO), 0), ii_hi = min(H - (ty0 - HALO), NI);
 
-    // the disparity as the low half of every key of the pass: held in one vector register, so that a key is that
-    // register and the one above it instead of a fresh copy of the scalar per key
-    // (one such register per slot: with a shared one the second key's cost would first be copied above it)
-    uint32_t d_lane[2] = {(uint32_t)d, (uint32_t)d};
-    asm volatile("" : "+v"(d_lane[0]));
-    asm volatile("" : "+v"(d_lane[1]));
+    // d in the position it has in the low word of a tile key (see PAIR_TILE_KEY_INIT)
+    const uint32_t d_sh = (uint32_t)d << 7;
     // fl(1 / (2r+1)^2) in a scalar register (as a literal it cannot be an operand of a packed multiply, and the
     // two slots would be scaled by two instructions)
     // Scaled passes: the window sums are (2r+1)^4 / unit times the result.  fl(1 / (2r+1)^4) has a relative error
@@ -500,12 +501,18 @@ __device__ __forceinline__ void pair_disparity_pass(
                                 a.q_out[((size_t)d * H + yo) * W + pl.x[j]] = tf;
                         }
                         if (!LEAN) tf = (tf == tf) ? tf : __int_as_float(0x7f800000);
-                        // The tile's keys are float64 patterns: high word = the cost's float32 pattern as it is, low
-                        // word = d.  The LDS unit's float64 minimum compares sign and magnitude, so the cost needs
-                        // no order-preserving integer map (two instructions per slot); the patterns are finite
-                        // float64 values for every float32 cost that is not NaN (a float32 infinity has the
-                        // exponent 0x7f8 of 0x7ff), and the low word breaks ties of equal costs.
-                        const double key = __hiloint2double(__float_as_int(tf), (int)d_lane[j]);
+                        // The tile's keys are float64 patterns, merged with the LDS unit's float64 minimum: it
+                        // compares sign and magnitude, so the cost's float32 pattern goes into the high word as it
+                        // is (no order-preserving integer map), and the patterns are finite float64 values for
+                        // every float32 cost that is not NaN (a float32 infinity has the exponent 0x7f8 of 0x7ff).
+                        // The low word breaks ties of equal costs in favour of the lower d: for a negative
+                        // cost the larger magnitude is the smaller number, so d has to enter inverted.  One
+                        // instruction does it: (d << 7) xor the cost's top byte sign-extended (an operand
+                        // select of the xor) -- bits 7.. hold d or ~d by the cost's sign, bits 0..6 exponent bits,
+                        // which are the same for all keys of one cost.
+                        const uint32_t cbits = __float_as_uint(tf);
+                        const uint32_t klo = d_sh ^ (uint32_t)((int32_t)cbits >> 24);
+                        const double key = __hiloint2double((int)cbits, (int)klo);
                         __hip_atomic_fetch_min(reinterpret_cast<LDS_AS double *>(keyg + k * TC + j * 64), key,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
         int gy = ty0 + o, gx = tx0 - HALO + c;
         if (c >= HALO && c < TC - HALO && gy < H && gx >= 0 && gx < W) {
             const uint64_t tile_key = t.key[o * TC + deint(c)];
-            uint64_t key = make_key(__uint_as_float((uint32_t)(tile_key >> 32)), (uint32_t)tile_key);
+            uint64_t key = pair_tile_key_to_key(tile_key);
             if (skipped_d != 0x7fffffff) {
                 const uint64_t kl = make_key(large_f, (uint32_t)skipped_d);
                 key = kl < key ? kl : key;
@@ -950,6 +957,7 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
                              float *d_q_out, hipStream_t s, const BandProgress *progress, float gate_eps,
                              float gate_min, bool precise, float gate_low) {
     if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
+    if (d_end > (1 << 24)) { set_error("two-column fused kernel: disparities up to 2^24"); return STEREO_EUNSUPPORTED; }
     FastArgs a;
     memset(&a, 0, sizeof(a));
     a.lw = d_lw; a.rw = d_rw; a.guide = d_guide; a.mean = d_mean; a.invden = d_invden; a.gmax = d_gmax;
