@@ -519,6 +519,30 @@ def test_exact_zero_cost_ties_take_the_lowest_disparity(rg, wct):
     assert np.mean(d_two[away] == d_gen[away]) >= 0.999
 
 
+@pytest.mark.parametrize("rg", [1, 3, 4])
+def test_equal_negative_costs_keep_the_lower_disparity(rg):
+    """A right image that repeats every 8 columns: the cost layers of d and d + 8 are identical wherever both are
+    valid, so every filtered cost -- the negative ones included (overshoot at the guide's edges) -- ties exactly
+    with its twins and the lowest disparity has to win.  The two-column kernel merges a tile's keys as float64
+    patterns, in which a negative cost reverses the order of the low word: its keys carry d inverted there."""
+    import stereo
+    rng = np.random.default_rng(11 + rg)
+    h, w, dmax, period = 96, 400, 24, 8
+    right = np.tile(rng.random((h, period)).astype(np.float32), (1, w // period))
+    left = np.roll(right, 3, axis=1).copy()   # left part: matches at d = 3, 11, 19 with zero cost ...
+    left[:, 200:] = rng.random((h, 200)).astype(np.float32) + 1.5          # ... next to a brighter part that matches nowhere:
+    left[48:, 100:200] = rng.random((48, 100)).astype(np.float32) * 0.3 + 2.0   # the filter overshoots below zero at the edges
+    run = lambda: stereo.compute_disparity(left, right, dmax, guided_radius=rg, guided_eps=0.0154, show_progress=False)
+    d_two, c_two = _with_kernel(0, run)
+    d_gen, c_gen = _with_kernel(1, run)
+    x0 = dmax + 4 + 4 * rg + 2                # from here on every window of every layer is valid
+    neg = c_two[:, x0:] < 0
+    assert neg.sum() >= 200, "the frame is meant to have negative filtered costs"
+    assert np.all(d_two[:, x0:][neg] == 3)
+    assert np.all(d_gen[:, x0:][c_gen[:, x0:] < 0] == 3)
+    assert rel_err(c_two, c_gen) <= 1e-6
+
+
 @pytest.mark.parametrize("filt,kw,okind,oradius,oparam,min_agree", [
     ("gaussian", {"gaussian_sigma": 1.0}, "FILTER_GAUSSIAN", 0, 1.0, 0.999),
     ("gaussian", {"gaussian_sigma": 0.6}, "FILTER_GAUSSIAN", 0, 0.6, 0.999),
