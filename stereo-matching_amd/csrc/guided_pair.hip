@@ -113,6 +113,17 @@ __device__ __forceinline__ void pair_disparity_pass(
     // work on a and b scaled by (2r+1)^2 / unit -- b' = sum(p) - a' mean(G) needs no product for its first
     // term -- and scale the result once per output; their other passes multiply `inv_post` back in.
     constexpr bool SCALED = LEAN && RG <= 3;
+    // 32-bit census words (radius <= 4): a cost is at most 1200 units, so the vertical sums (<= 8400) and the
+    // window sums (<= 58800) of the two slots share one register, 16 bits each: half the adds and lane shifts.
+    // 64-bit census words (radius <= 8): a valid cost is at most 2040 units, so passes without `large` costs (the
+    // lean ones) pack as well up to guided radius 3 ((r+1) lanes x (2r+1) rows x 2040 < 2^16).
+    constexpr bool PACK16 = !WORD64 || (LEAN && RG <= 3);
+#ifndef FP_NO_MAGIC
+    constexpr bool MAGIC = PACK16 && !PRECISE;
+#else
+    constexpr bool MAGIC = false;
+#endif
+    constexpr uint32_t MAGIC_BITS = MAGIC ? 0x4B000000u : 0u;
     using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
     const int H = a.H, W = a.W, R = a.radius;
     const WordT *rw = static_cast<const WordT *>(a.rw);
@@ -131,26 +142,17 @@ __device__ __forceinline__ void pair_disparity_pass(
     float rcp_full_s = a.lean_scale;
     asm volatile("" : "+s"(rcp_full_s));
     const double lean_scale_d = SCALED ? (double)a.unit / (double)(WIN * WIN * WIN * WIN) : 1.0 / (double)(WIN * WIN);
+    // (the selectable costs carry the bits of 2^23 like the computed ones, see MAGIC)
     uint32_t large_lane[2];
     bool xd_valid[2];
     unsigned roff[2];  // byte offset of the right census word inside its row
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        large_lane[j] = pl.x_in[j] ? a.large_units : 0u;
+        large_lane[j] = (pl.x_in[j] ? a.large_units : 0u) | MAGIC_BITS;
         xd_valid[j] = pl.x_valid[j] && (pl.x[j] - d >= R);
         roff[j] = (unsigned)min(max(pl.x[j] - d, 0), W - 1) * (unsigned)sizeof(WordT);
     }
 
-    // 32-bit census words (radius <= 4): a cost is at most 1200 units, so the vertical sums (<= 8400) and the
-    // window sums (<= 58800) of the two slots share one register, 16 bits each: half the adds and lane shifts.
-    // 64-bit census words (radius <= 8): a valid cost is at most 2040 units, so passes without `large` costs (the
-    // lean ones) pack as well up to guided radius 3 ((r+1) lanes x (2r+1) rows x 2040 < 2^16).
-    constexpr bool PACK16 = !WORD64 || (LEAN && RG <= 3);
-#ifndef FP_NO_MAGIC
-    constexpr bool MAGIC = LEAN && PACK16 && !PRECISE;
-#else
-    constexpr bool MAGIC = false;
-#endif
     uint32_t C1[2] = {0u, 0u};
     uint32_t C1p = 0u, prp[WIN];
     int I2[2] = {0, 0};
@@ -189,7 +191,10 @@ __device__ __forceinline__ void pair_disparity_pass(
     RowHead cur;
     bool have_head = false;
     // right census words come from global memory (L2): they are requested RPF rows ahead
-    constexpr int RPF = 3;
+#ifndef FP_RPF
+#define FP_RPF 3
+#endif
+    constexpr int RPF = FP_RPF;
     WordT rq[RPF][2];
     // buffer loads: the row offset travels in a scalar register and the lane's column offset in
     // one 32-bit register, so no 64-bit address arithmetic is spent per row
@@ -288,7 +293,7 @@ __device__ __forceinline__ void pair_disparity_pass(
                 // MAGIC: the cost is formed on top of the pattern of 2^23, so that the same register read as a float32
                 // is 2^23 + cost exactly (no integer-to-float conversion per slot: one packed subtraction for both);
                 // the 24-bit multiply and the 16-bit packing below read the low bits, which are the cost itself
-                const uint32_t fs = field_sum((WordT)(cur.L[j] ^ Rcur[j]), MAGIC ? 0x4B000000u : 0u);
+                const uint32_t fs = field_sum((WordT)(cur.L[j] ^ Rcur[j]), MAGIC_BITS);
                 uint32_t p;
                 if (LEAN) {
                     p = fs;
@@ -298,7 +303,7 @@ __device__ __forceinline__ void pair_disparity_pass(
                     const bool rowv = i >= iv_lo && i < iv_hi;
                     const bool rowi = i >= ii_lo && i < ii_hi;
                     p = (rowv && xd_valid[j]) ? fs : large_lane[j];
-                    p = rowi ? p : 0u;
+                    p = rowi ? p : MAGIC_BITS;
                 }
                 int kp = __mul24(cur.k[j], (int)p);
                 asm volatile("" : "+v"(kp));  // one multiply: the running sum adds kp instead of re-deriving it
