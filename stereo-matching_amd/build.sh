@@ -6,9 +6,9 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 OUT="$HERE/libstereo_hip.so"
 SRCS=("$HERE"/csrc/*.hip)
 mkdir -p "$HERE/csrc/obj"
-# Build id = hash of every source that goes into the library; stereo_hip_version() reports it, so that a counter
+# Build id = hash of every source that goes into the library and of this script (the compiler flags); stereo_hip_version() reports it, so that a counter
 # summary under profiles/ can be matched with the library it was taken on.
-BUILD_ID="$(cat "$HERE"/csrc/*.hip "$HERE"/csrc/*.hpp "$HERE/../include/stereo_hip.h" | sha256sum | cut -c1-12)"
+BUILD_ID="$(cat "$HERE"/csrc/*.hip "$HERE"/csrc/*.hpp "$HERE/../include/stereo_hip.h" "$HERE/build.sh" | sha256sum | cut -c1-12)"
 if [[ "$(cat "$HERE/csrc/obj/build_id.txt" 2>/dev/null)" != "$BUILD_ID" ]]; then
   rm -f "$HERE/csrc/obj/api.o"
   echo "$BUILD_ID" > "$HERE/csrc/obj/build_id.txt"
@@ -18,12 +18,16 @@ pids=()
 for src in "${SRCS[@]}"; do
   obj="$HERE/csrc/obj/$(basename "${src%.hip}").o"
   OBJS+=("$obj")
-  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$HERE/csrc/common.hpp" -nt "$obj" || "$HERE/csrc/census_dev.hpp" -nt "$obj" || "$HERE/csrc/fast_common.hpp" -nt "$obj" || "$HERE/../include/stereo_hip.h" -nt "$obj" ]]; then
+  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$HERE/csrc/common.hpp" -nt "$obj" || "$HERE/csrc/census_dev.hpp" -nt "$obj" || "$HERE/csrc/fast_common.hpp" -nt "$obj" || "$HERE/../include/stereo_hip.h" -nt "$obj" || "$HERE/build.sh" -nt "$obj" ]]; then
     # The fused kernels keep two independent columns per lane in scalar registers: packing them into
     # v_pk_* instructions costs register shuffles and issues no faster on gfx950.
     file_flags=""
     case "$(basename "$src")" in
-      guided_pair.hip|guided_fast.hip) file_flags="-fno-slp-vectorize" ;;
+      # (two-column kernel: it runs two wavefronts per SIMD whatever its register count, so the default scheduler's
+      #  care for occupancy buys nothing; same-box runs of library copies: the strategy that clusters memory
+      #  operations 0.9 % faster than the default, the one that favours instruction-level parallelism 0.5 %)
+      guided_pair.hip) file_flags="-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-memory-clause" ;;
+      guided_fast.hip) file_flags="-fno-slp-vectorize" ;;
       api.hip) file_flags="-DSTEREO_BUILD_ID=\"$BUILD_ID\"" ;;
     esac
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$HERE/../include" -I"$HERE/csrc" \

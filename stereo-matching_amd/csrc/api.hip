@@ -204,7 +204,7 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         const bool pair_cfg = fused_pair_supported(cfg, p->guided_radius) && (g_force_kernel == 0 || g_force_kernel == 3);
         const bool pair = pair_cfg && g_force_kernel == 0 && eps_ok;
         // the same kernel with a float64 second stage: eps from PRECISE_KERNEL_MIN_EPS up to the fast kernels' limit
-        const bool pair_precise = pair_cfg && (g_force_kernel == 3 || p->guided_eps >= PRECISE_KERNEL_MIN_EPS);
+        const bool pair_precise = pair_cfg && p->guided_radius <= 4 && (g_force_kernel == 3 || p->guided_eps >= PRECISE_KERNEL_MIN_EPS);
         const bool fast = !pair_cfg && fused_fast_supported(cfg, p->guided_radius) && g_force_kernel != 1 && eps_ok;
         const int slices = (pair || pair_precise) ? fused_pair_slices(H, W, p->guided_radius, cfg.word64 != 0, d_end - d_begin)
                            : fast ? fused_fast_slices(H, W, p->guided_radius, d_end - d_begin) : 1;

@@ -117,7 +117,8 @@ __device__ __forceinline__ void pair_disparity_pass(
     // window sums (<= 58800) of the two slots share one register, 16 bits each: half the adds and lane shifts.
     // 64-bit census words (radius <= 8): a valid cost is at most 2040 units, so passes without `large` costs (the
     // lean ones) pack as well up to guided radius 3 ((r+1) lanes x (2r+1) rows x 2040 < 2^16).
-    constexpr bool PACK16 = !WORD64 || (LEAN && RG <= 3);
+    // Guided radius 5 (32-bit words): (r+1) (2r+1) 1200 exceeds 16 bits, so only its passes without `large` costs pack.
+    constexpr bool PACK16 = WORD64 ? (LEAN && RG <= 3) : (RG <= 4 || LEAN);
 #ifndef FP_NO_MAGIC
     constexpr bool MAGIC = PACK16 && !PRECISE;
 #else
@@ -479,7 +480,7 @@ __device__ __forceinline__ void pair_disparity_pass(
                     //    the reciprocal, exact whenever the quotient is representable.  Either way constant `large`
                     //    windows stay exact ties.
                     const f2 t32 = sum;
-                    if (LEAN) {
+                    if (LEAN && RG <= 4) {   // (fl(1 / 121) is not close enough: radius 5 divides like the clipped windows)
                         // (two plain multiplies: each result is the high word of its slot's key, see below)
                         qv.x = t32.x * rcp_full_s;
                         qv.y = t32.y * rcp_full_s;
@@ -588,8 +589,10 @@ __global__ __launch_bounds__(256) void pair_fill_split_keys_kernel(uint64_t *__r
     }
 }
 
+// (one workgroup of 8 wavefronts per compute unit -- the tile image fills the LDS -- is two wavefronts per SIMD:
+//  said to the compiler, so that its scheduler does not hold back for an occupancy the kernel cannot have)
 template <int RG, bool WORD64, int TH, int NW, bool QOUT>
-__global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_guided_pair_kernel(FastArgs a) {
     constexpr int WIN = 2 * RG + 1;
     constexpr int HALO = 2 * RG;
     constexpr int NI = TH + 4 * RG;
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_pair_kernel(FastArgs a) 
             atomicMin(&t.next_d[1], d);
             continue;
         }
-        if (precise) {
+        if (RG <= 4 && precise) {   // (radius 5 has no precise variant: its rings would not fit the registers)
             if (lean_tile && xlo - d >= R)
                 pair_disparity_pass<RG, WORD64, TH, QOUT, 2, true>(a, t, d, lane, ty0, pl, inv_scale_d, inv_post);
             else if (interior)
@@ -864,13 +867,14 @@ int pair_tile_height(int guided_radius, bool word64) {
         case 2: return word64 ? PairTile<2, true>::TH : PairTile<2, false>::TH;
         case 3: return word64 ? PairTile<3, true>::TH : PairTile<3, false>::TH;
         case 4: return word64 ? PairTile<4, true>::TH : PairTile<4, false>::TH;
+        case 5: return word64 ? PairTile<5, true>::TH : PairTile<5, false>::TH;
         default: return 0;
     }
 }
 
 bool fused_pair_supported(const CensusCfg &cfg, int guided_radius) {
     // (radius 1 included: 2.50 against 2.76 ms for the one-column kernel on a 2964 x 2000 frame with 270 disparities)
-    return cfg.exact && guided_radius >= 1 && guided_radius <= 4 && cfg.unit > 0.f;
+    return cfg.exact && guided_radius >= 1 && guided_radius <= 5 && cfg.unit > 0.f;
 }
 
 int fused_pair_slices(int H, int W, int guided_radius, bool word64, int n_disp) {
@@ -997,7 +1001,7 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
         const int ny = th > 0 ? ceil_div(H, th) : 0;
         const Key key = {W, H, guided_radius, w64 ? 1 : 0, cfg.radius, d_begin, d_end,
                          a.band_tile_rows > 0 ? a.band_tile_rows : ny, device_compute_units()};
-        if (th > 0 && guided_radius >= 1 && guided_radius <= 4) {
+        if (th > 0 && guided_radius >= 1 && guided_radius <= 5) {
             std::lock_guard<std::mutex> lock(mu);
             if (memcmp(&key, &last_key, sizeof(Key)) != 0) {
                 last_plan = plan_tail_split(W, H, th, guided_radius, cfg.radius, d_begin, d_end, key.band_rows, key.units);
@@ -1019,7 +1023,8 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
         case 2: return w64 ? launch_pair_t<2, true>(a, s) : launch_pair_t<2, false>(a, s);
         case 3: return w64 ? launch_pair_t<3, true>(a, s) : launch_pair_t<3, false>(a, s);
         case 4: return w64 ? launch_pair_t<4, true>(a, s) : launch_pair_t<4, false>(a, s);
-        default: set_error("fast fused guided kernel supports radius 1..4"); return STEREO_EUNSUPPORTED;
+        case 5: return w64 ? launch_pair_t<5, true>(a, s) : launch_pair_t<5, false>(a, s);
+        default: set_error("fast fused guided kernel supports radius 1..5"); return STEREO_EUNSUPPORTED;
     }
 }
 

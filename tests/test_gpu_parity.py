@@ -255,17 +255,19 @@ def test_filtered_layers_match_oracle(oracle):
     assert worst <= 1e-6, worst
 
 
-def test_disparity_shards_merge_bit_exact():
+@pytest.mark.parametrize("rg", [3, 5])
+def test_disparity_shards_merge_bit_exact(rg):
     """Any partition of [0, D) merged with the lexicographic (cost, d) min equals the unsharded run."""
     import stereo
     from synth import synth_pair_gray
     left, right, _ = synth_pair_gray(90, 160, 48, seed=21)
-    d_all, c_all = stereo.compute_disparity(left, right, 48, guided_eps=0.0154, show_progress=False)
+    kw = dict(guided_radius=rg, guided_eps=0.0154, show_progress=False)
+    d_all, c_all = stereo.compute_disparity(left, right, 48, **kw)
     for cuts in ([0, 24, 48], [0, 5, 6, 30, 48], [0, 48, 48]):
         best_c = np.full(c_all.shape, np.inf, dtype=np.float32)
         best_d = np.zeros(d_all.shape, dtype=np.int32)
         for a, b in zip(cuts[:-1], cuts[1:]):
-            d, c = stereo.compute_disparity(left, right, 48, guided_eps=0.0154, show_progress=False, d_begin=a, d_end=b)
+            d, c = stereo.compute_disparity(left, right, 48, d_begin=a, d_end=b, **kw)
             better = (c < best_c) | ((c == best_c) & (d < best_d) & np.isfinite(c))
             best_c = np.where(better, c, best_c)
             best_d = np.where(better, d, best_d)
@@ -425,7 +427,7 @@ def test_fused_kernel_variants_agree(shape):
 
 
 @pytest.mark.parametrize("eps", [1e-5, 1e-4, 1e-3, 5e-3, 7.9e-3])
-@pytest.mark.parametrize("rg,wct", [(2, 4), (3, 4), (4, 4), (3, 8)])
+@pytest.mark.parametrize("rg,wct", [(2, 4), (3, 4), (4, 4), (3, 8), (5, 4), (5, 8)])   # (radius 5: the general kernel serves small eps)
 def test_guided_small_eps_takes_the_precise_kernel(oracle, eps, rg, wct):
     """eps between 1e-4 and 8e-3 (for guides in [0, 1]): the two-column kernel's precise variant (float64 where the
     fast one has float32), on a frame with interior tiles, against the oracle; and the same frame through the general
@@ -467,7 +469,7 @@ def test_fused_guided_conditioning(oracle, scale):
 
 
 @pytest.mark.parametrize("base_weight", [8.0, 2.0, 6.0, 3.0, 12.0])
-@pytest.mark.parametrize("rg", [1, 2, 3, 4])
+@pytest.mark.parametrize("rg", [1, 2, 3, 4, 5])
 def test_cost_units_and_interior_tiles(oracle, base_weight, rg):
     """Frames with tiles away from every border (the two-column kernel's passes on full windows), for cost units
     that are powers of two (base weights 8, 2) and exactly summable ones that are not (6, 3, 12), whose tiles take
@@ -519,7 +521,7 @@ def test_exact_zero_cost_ties_take_the_lowest_disparity(rg, wct):
     assert np.mean(d_two[away] == d_gen[away]) >= 0.999
 
 
-@pytest.mark.parametrize("rg", [1, 3, 4])
+@pytest.mark.parametrize("rg", [1, 3, 4, 5])
 def test_equal_negative_costs_keep_the_lower_disparity(rg):
     """A right image that repeats every 8 columns: the cost layers of d and d + 8 are identical wherever both are
     valid, so every filtered cost -- the negative ones included (overshoot at the guide's edges) -- ties exactly
