@@ -25,8 +25,10 @@ for src in "${SRCS[@]}"; do
     case "$(basename "$src")" in
       # (two-column kernel: it runs two wavefronts per SIMD whatever its register count, so the default scheduler's
       #  care for occupancy buys nothing; same-box runs of library copies: the strategy that clusters memory
-      #  operations 0.9 % faster than the default, the one that favours instruction-level parallelism 0.5 %)
-      guided_pair.hip) file_flags="-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-memory-clause" ;;
+      #  operations 0.9 % faster than the default, the one that favours instruction-level parallelism 0.5 %;
+      #  relaxed occupancy another 0.55 %.  The post-RA scheduler stays as it is: without it + 5.5 %, bottom-up
+      #  + 2.5 %, bidirectional + 6 %)
+      guided_pair.hip) file_flags="-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-memory-clause -mllvm -amdgpu-schedule-relaxed-occupancy=true" ;;
       guided_fast.hip) file_flags="-fno-slp-vectorize" ;;
       api.hip) file_flags="-DSTEREO_BUILD_ID=\"$BUILD_ID\"" ;;
     esac

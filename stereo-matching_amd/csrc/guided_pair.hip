@@ -26,6 +26,12 @@
 
 namespace shp {
 
+// Empty asm statements pin values in registers against re-association.
+#ifdef FP_ASM_PLAIN
+#define FP_PIN asm
+#else
+#define FP_PIN asm volatile
+#endif
 template <typename WordT>
 struct PairLds {
     double *mG;      // [NJ][128] box mean of the guide
@@ -307,7 +313,7 @@ __device__ __forceinline__ void pair_disparity_pass(
                     p = rowi ? p : MAGIC_BITS;
                 }
                 int kp = __mul24(cur.k[j], (int)p);
-                asm volatile("" : "+v"(kp));  // one multiply: the running sum adds kp instead of re-deriving it
+                FP_PIN("" : "+v"(kp));  // one multiply: the running sum adds kp instead of re-deriving it
                 pf[j] = MAGIC ? __uint_as_float(p) : (float)p;
                 if (!PACK16) { C1[j] += p; pr[j][k] = p; }
                 I2[j] += kp;
@@ -367,8 +373,8 @@ __device__ __forceinline__ void pair_disparity_pass(
                 // (the integer partial sums are pinned: re-associated, each three-operand add would need its
                 //  lane-shifted operands as separate move instructions)
                 //  (only the sums the variant uses: a pinned unused one costs a move of its zero per row)
-                if (PACK16) asm volatile("" : "+v"(ci), "+v"(di), "+v"(cp));
-                else asm volatile("" : "+v"(e1), "+v"(o1), "+v"(ci), "+v"(di));
+                if (PACK16) FP_PIN("" : "+v"(ci), "+v"(di), "+v"(cp));
+                else FP_PIN("" : "+v"(e1), "+v"(o1), "+v"(ci), "+v"(di));
                 uint32_t s1[2];
                 int si[2];
                 float sf[2];
