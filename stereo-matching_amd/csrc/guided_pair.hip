@@ -26,12 +26,8 @@
 
 namespace shp {
 
-// Empty asm statements pin values in registers against re-association.
-#ifdef FP_ASM_PLAIN
-#define FP_PIN asm
-#else
+// Empty asm statements pin values in registers against re-association (volatile: the plain form measured no faster).
 #define FP_PIN asm volatile
-#endif
 template <typename WordT>
 struct PairLds {
     double *mG;      // [NJ][128] box mean of the guide
@@ -125,11 +121,7 @@ __device__ __forceinline__ void pair_disparity_pass(
     // lean ones) pack as well up to guided radius 3 ((r+1) lanes x (2r+1) rows x 2040 < 2^16).
     // Guided radius 5 (32-bit words): (r+1) (2r+1) 1200 exceeds 16 bits, so only its passes without `large` costs pack.
     constexpr bool PACK16 = WORD64 ? (LEAN && RG <= 3) : (RG <= 4 || LEAN);
-#ifndef FP_NO_MAGIC
     constexpr bool MAGIC = PACK16 && !PRECISE;
-#else
-    constexpr bool MAGIC = false;
-#endif
     constexpr uint32_t MAGIC_BITS = MAGIC ? 0x4B000000u : 0u;
     using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
     const int H = a.H, W = a.W, R = a.radius;
@@ -139,8 +131,8 @@ __device__ __forceinline__ void pair_disparity_pass(
 
     // d in the position it has in the low word of a tile key (see PAIR_TILE_KEY_INIT)
     const uint32_t d_sh = (uint32_t)d << 7;
-    // fl(1 / (2r+1)^2) in a scalar register (as a literal it cannot be an operand of a packed multiply, and the
-    // two slots would be scaled by two instructions)
+    // The factor from a full window's sum to the filtered cost, in a scalar register (one operand of the two
+    // multiplies that write the keys' high words).  Unscaled passes: fl(1 / (2r+1)^2).
     // Scaled passes: the window sums are (2r+1)^4 / unit times the result.  fl(1 / (2r+1)^4) has a relative error
     // below 2^-25 for r = 1..3, so a window of equal costs (the sum is (2r+1)^4 times the cost in units, exact)
     // still gives exactly that cost; the cost unit, a power of two, goes into the same factor (with any other
@@ -198,10 +190,7 @@ __device__ __forceinline__ void pair_disparity_pass(
     RowHead cur;
     bool have_head = false;
     // right census words come from global memory (L2): they are requested RPF rows ahead
-#ifndef FP_RPF
-#define FP_RPF 3
-#endif
-    constexpr int RPF = FP_RPF;
+    constexpr int RPF = 3;   // (2 and 4 measured within 0.3 % of it)
     WordT rq[RPF][2];
     // buffer loads: the row offset travels in a scalar register and the lane's column offset in
     // one 32-bit register, so no 64-bit address arithmetic is spent per row
@@ -555,12 +544,8 @@ struct TilePos { int x, y, band, band_rows; };
 // column: at the left edge the slack shortens the disparity loops of the first tile columns, at the right edge the
 // partly empty tile would cost as much as a full one.  Even, so that an image column keeps its slot in the lane.
 __host__ __device__ inline int pair_x_shift(int W, int tile_width) {
-#ifdef FP_NO_XSHIFT
-    return 0;
-#else
     const int nx = (W + tile_width - 1) / tile_width;
     return (nx * tile_width - W) & ~1;
-#endif
 }
 __host__ __device__ inline TilePos pair_tile_of_index(int index, int nx, int ny, int band_rows_max) {
     TilePos p;
