@@ -30,10 +30,10 @@ namespace shp {
 #define FP_PIN asm volatile
 template <typename WordT>
 struct PairLds {
-    double *mG;      // [NJ][128] box mean of the guide
+    double *mG;      // [NJ][128] box mean of the guide, rows shifted by r (element c + r = tile column c)
     uint64_t *key;   // [TH][128] packed (cost, d)
     WordT *L;        // [NI][128] left census words
-    float *inv;      // [NJ][128] cost unit / ((var + eps) * window area): a and b come out in cost units
+    float *inv;      // [NJ][128] cost unit / ((var + eps) * window area): a and b come out in cost units; rows shifted like mG
     float *glo;      // [NI][128] guide - k * 2^-s
     float *gout;     // [TH][128] (+pad) guide at the output pixels
     int *next_d;     // [0] next disparity to hand out, [1] lowest disparity whose costs are all `large`
@@ -226,10 +226,10 @@ __device__ __forceinline__ void pair_disparity_pass(
         LDS_AS const uint32_t *kg = lds_lane_ptr(reinterpret_cast<const uint32_t *>(t.k + base * TC + 2 * lane));
         LDS_AS const Pair<float> *glog = lds_lane_ptr(reinterpret_cast<const Pair<float> *>(t.glo + base * TC + 2 * lane));
         // stage-1 columns 2l - r and 2l - r + 1 of the two slots (r odd: odd column first)
-        LDS_AS const double *mGg0 = lds_lane_ptr(t.mG + (base - HALO) * TC + pl.c1);
-        LDS_AS const double *mGg1 = lds_lane_ptr(t.mG + (base - HALO) * TC + pl.c1b);
-        LDS_AS const float *invg0 = lds_lane_ptr(t.inv + (base - HALO) * TC + pl.c1);
-        LDS_AS const float *invg1 = lds_lane_ptr(t.inv + (base - HALO) * TC + pl.c1b);
+        // (rows of mG and inv are stored shifted by r: element 2l + j is stage-1 column 2l - r + j, so a lane's two
+        //  values are one 16-byte / 8-byte read)
+        LDS_AS const Pair<double> *mGp = lds_lane_ptr(reinterpret_cast<const Pair<double> *>(t.mG + (base - HALO) * TC + 2 * lane));
+        LDS_AS const Pair<float> *invp = lds_lane_ptr(reinterpret_cast<const Pair<float> *>(t.inv + (base - HALO) * TC + 2 * lane));
         LDS_AS const Pair<float> *goutg = lds_lane_ptr(reinterpret_cast<const Pair<float> *>(t.gout + (base - 2 * HALO) * TC + 2 * lane));
         LDS_AS uint64_t *keyg = lds_lane_ptr(t.key + (base - 2 * HALO) * TC + lane);
         auto fetch_head = [&](int k) {
@@ -240,7 +240,8 @@ __device__ __forceinline__ void pair_disparity_pass(
             r.L[0] = lp.x; r.L[1] = lp.y;
             r.k[0] = (int)(short)(kk & 0xffffu); r.k[1] = (int)kk >> 16;
             r.glo = gp;
-            r.mG[0] = mGg0[k * TC]; r.mG[1] = mGg1[k * TC];
+            const Pair<double> mp = mGp[k * (TC / 2)];
+            r.mG[0] = mp.x; r.mG[1] = mp.y;
             if (PRECISE) {
                 const int gy = min(max(ty0 - RG + base + k - HALO, 0), H - 1);
                 const int soff = gy * W * (int)sizeof(double);
@@ -250,7 +251,8 @@ __device__ __forceinline__ void pair_disparity_pass(
                     r.inv_d[j] = __hiloint2double((int)v[1], (int)v[0]);
                 }
             } else {
-                r.inv_f[0] = invg0[k * TC]; r.inv_f[1] = invg1[k * TC];
+                const Pair<float> ip = invp[k * (TC / 2)];
+                r.inv_f[0] = ip.x; r.inv_f[1] = ip.y;
             }
             return r;
         };
@@ -701,10 +703,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int gy = ty0 - RG + j;
             const bool in = x_in && gy >= 0 && gy < H;
             const double mg = in ? m_in[u] : 0.0;
-            t.mG[j * TC + deint(c)] = mg;
+            // stage-1 column c is element c + r of its row (see the row loop); the first r elements, which only the
+            // unused results of the first lanes read, are zero
+            if (c + RG < TC) t.mG[j * TC + c + RG] = mg;
+            if (c < RG) t.mG[j * TC + c] = 0.0;
             const int cyy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1, cxx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
             const float iv = !in ? 0.f : scaled_tile ? (float)d_in[u] : (float)(d_in[u] * (double)a.unit / (double)(cyy * cxx));
-            t.inv[j * TC + deint(c)] = iv;
+            if (c + RG < TC) t.inv[j * TC + c + RG] = iv;
+            if (c < RG) t.inv[j * TC + c] = 0.f;
             finite_in = finite_in && fabs(mg) <= 1.0e300 && fabsf(iv) <= 3.0e38f;
         }
     }
