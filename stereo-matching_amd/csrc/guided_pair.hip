@@ -32,7 +32,8 @@ template <typename WordT>
 struct PairLds {
     double *mG;      // [NJ][128] box mean of the guide, rows shifted by r (element c + r = tile column c)
     uint64_t *key;   // [TH][128] packed (cost, d)
-    WordT *L;        // [NI][128] left census words
+    WordT *L;        // [NI][128] left census words.  32-bit words: L and glo are ONE array of 16-byte records per
+                     // lane and row, (L(2l), L(2l+1), glo(2l), glo(2l+1)), so that a lane's four values are one LDS read
     float *inv;      // [NJ][128] cost unit / ((var + eps) * window area): a and b come out in cost units; rows shifted like mG
     float *glo;      // [NI][128] guide - k * 2^-s
     float *gout;     // [TH][128] (+pad) guide at the output pixels
@@ -61,6 +62,7 @@ using Pair = T __attribute__((ext_vector_type(2)));  // the two slots of a lane,
 // The float32 arithmetic of the two slots is written on pairs: with two wavefronts per SIMD every
 // vector instruction costs one issue slot, so a packed instruction halves the cost of the pair.
 using f2 = Pair<float>;
+using LdsRec = uint32_t __attribute__((ext_vector_type(4)));   // (L(2l), L(2l+1), glo(2l), glo(2l+1)) of a lane and row
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 // {a.y * b.x + c.y, a.y * b.y + c.y}: the high halves of a and c serve both results.  Written as the instruction
 // with its operand selects: from the vector expression the compiler first copies a.y and c.y into low halves.
@@ -222,9 +224,10 @@ __device__ __forceinline__ void pair_disparity_pass(
     }
     auto row_group = [&](const int base, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
-        LDS_AS const Pair<WordT> *Lg = lds_lane_ptr(reinterpret_cast<const Pair<WordT> *>(t.L + base * TC + 2 * lane));
+        LDS_AS const Pair<WordT> *Lg = WORD64 ? lds_lane_ptr(reinterpret_cast<const Pair<WordT> *>(t.L + base * TC + 2 * lane)) : nullptr;
+        LDS_AS const LdsRec *LGg = WORD64 ? nullptr : lds_lane_ptr(reinterpret_cast<const LdsRec *>(reinterpret_cast<const uint32_t *>(t.L) + base * 2 * TC + 4 * lane));
         LDS_AS const uint32_t *kg = lds_lane_ptr(reinterpret_cast<const uint32_t *>(t.k + base * TC + 2 * lane));
-        LDS_AS const Pair<float> *glog = lds_lane_ptr(reinterpret_cast<const Pair<float> *>(t.glo + base * TC + 2 * lane));
+        LDS_AS const Pair<float> *glog = WORD64 ? lds_lane_ptr(reinterpret_cast<const Pair<float> *>(t.glo + base * TC + 2 * lane)) : nullptr;
         // stage-1 columns 2l - r and 2l - r + 1 of the two slots (r odd: odd column first)
         // (rows of mG and inv are stored shifted by r: element 2l + j is stage-1 column 2l - r + j, so a lane's two
         //  values are one 16-byte / 8-byte read)
@@ -234,12 +237,17 @@ __device__ __forceinline__ void pair_disparity_pass(
         LDS_AS uint64_t *keyg = lds_lane_ptr(t.key + (base - 2 * HALO) * TC + lane);
         auto fetch_head = [&](int k) {
             RowHead r;
-            const Pair<WordT> lp = Lg[k * (TC / 2)];
             const uint32_t kk = kg[k * (TC / 2)];
-            const Pair<float> gp = glog[k * (TC / 2)];
-            r.L[0] = lp.x; r.L[1] = lp.y;
+            if constexpr (WORD64) {
+                const Pair<WordT> lp = Lg[k * (TC / 2)];
+                r.L[0] = lp.x; r.L[1] = lp.y;
+                r.glo = glog[k * (TC / 2)];
+            } else {
+                const LdsRec rec = LGg[k * (TC / 2)];
+                r.L[0] = rec.x; r.L[1] = rec.y;
+                r.glo = f2{__uint_as_float(rec.z), __uint_as_float(rec.w)};
+            }
             r.k[0] = (int)(short)(kk & 0xffffu); r.k[1] = (int)kk >> 16;
-            r.glo = gp;
             const Pair<double> mp = mGp[k * (TC / 2)];
             r.mG[0] = mp.x; r.mG[1] = mp.y;
             if (PRECISE) {
@@ -601,8 +609,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     t.mG = reinterpret_cast<double *>(sp); sp += sizeof(double) * NJ * TC;
     t.key = reinterpret_cast<uint64_t *>(sp); sp += sizeof(uint64_t) * TH * TC;
     t.L = reinterpret_cast<WordT *>(sp); sp += sizeof(WordT) * NI * TC;
+    t.glo = reinterpret_cast<float *>(sp); sp += sizeof(float) * NI * TC;   // (32-bit words: one array of records with L, see PairLds)
     t.inv = reinterpret_cast<float *>(sp); sp += sizeof(float) * NJ * TC;
-    t.glo = reinterpret_cast<float *>(sp); sp += sizeof(float) * NI * TC;
     t.gout = reinterpret_cast<float *>(sp); sp += sizeof(float) * (TH * TC + 16);
     t.next_d = reinterpret_cast<int *>(sp); sp += 16;
     t.k = reinterpret_cast<short *>(sp);
@@ -691,8 +699,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             finite_in = finite_in && fabsf(g) <= 3.0e38f;
             const int kk = __float2int_rn(g * scale_f);
             t.k[idx] = (short)kk;
-            t.glo[idx] = fmaf(-(float)kk, inv_scale_f, g);
-            t.L[idx] = in ? l_in[u] : WordT(0);
+            const float glo_v = fmaf(-(float)kk, inv_scale_f, g);
+            if constexpr (WORD64) {
+                t.glo[idx] = glo_v;
+                t.L[idx] = in ? l_in[u] : WordT(0);
+            } else {
+                uint32_t *rec = reinterpret_cast<uint32_t *>(t.L) + i * 2 * TC + (c >> 1) * 4 + (c & 1);
+                rec[0] = in ? (uint32_t)l_in[u] : 0u;
+                rec[2] = __float_as_uint(glo_v);
+            }
             const int o = i - HALO;
             if (o >= 0 && o < TH) t.gout[o * TC + c] = g;
         }
