@@ -225,6 +225,28 @@ def compute_disparity_allcores(left: np.ndarray, right: np.ndarray, dmax: int, w
     return disp, cost
 
 
+def compute_disparity_query(left: np.ndarray, right: np.ndarray, dmax: int, query_disp: np.ndarray, wct_radius: int = 4,
+                            base_weight: float = 8.0, radius: int = 3, eps: float = 0.0154, threads: int = 0):
+    """compute_disparity_allcores plus the oracle's own filtered cost at a queried disparity per pixel:
+    returns (disparity, min_cost, F[y, x, query_disp[y, x]]).  For gap-aware comparisons at sizes where the
+    dmax filtered layers cannot be kept."""
+    l = np.ascontiguousarray(left, dtype=np.float32)
+    r = np.ascontiguousarray(right, dtype=np.float32)
+    h, w = l.shape
+    q = np.ascontiguousarray(query_disp, dtype=np.int32)
+    if q.shape != (h, w):
+        raise ValueError("query_disp must have the image's shape")
+    disp = np.empty((h, w), dtype=np.int32)
+    cost = np.empty((h, w), dtype=np.float32)
+    qcost = np.empty((h, w), dtype=np.float32)
+    rc = lib().orc_compute_disparity_query(_ptr(l), _ptr(r), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(dmax),
+                                           ctypes.c_int(wct_radius), ctypes.c_double(base_weight), ctypes.c_int(radius),
+                                           ctypes.c_double(eps), _ptr(disp), _ptr(cost), _ptr(q), _ptr(qcost),
+                                           ctypes.c_int(threads or max_threads()))
+    _check(rc, "compute_disparity_query")
+    return disp, cost, qcost
+
+
 # ---- steps either side of the hot path (numpy restatements; test infrastructure only) ----------
 def to_gray(image: np.ndarray, normalize: bool = False, max_value=None) -> np.ndarray:
     """Reference stereo_io.py:47-75 with stereo_io.py:22-44 for the scale: float32 products and

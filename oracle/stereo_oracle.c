@@ -576,9 +576,10 @@ int orc_compute_disparity(const float *left, const float *right, int height, int
  * results are merged by (cost, d) -- strict '<', ties to the lower disparity.  Every layer goes through
  * the same arithmetic as in orc_aggregate_and_wta, so the result is bit-identical; only the schedule
  * differs.  Timed by bench.py as the all-cores CPU figure.  Guided filter only. */
-int orc_compute_disparity_allcores(const float *left, const float *right, int height, int width, int dmax,
-                                   int wct_radius, double base_weight, int radius, double eps,
-                                   int32_t *disparity, float *min_cost, int threads) {
+static int compute_disparity_allcores_impl(const float *left, const float *right, int height, int width, int dmax,
+                                           int wct_radius, double base_weight, int radius, double eps,
+                                           int32_t *disparity, float *min_cost, const int32_t *query_disp,
+                                           float *query_cost, int threads) {
     size_t n = (size_t)height * width;
     if (threads < 1) threads = 1;
     if (threads > dmax) threads = dmax;
@@ -619,6 +620,11 @@ int orc_compute_disparity_allcores(const float *left, const float *right, int he
                         break;
                     }
                     orc_wta_update(filtered, n, d, mc, md);
+                    /* the filtered cost of layer d at the pixels whose queried disparity is d (each pixel belongs
+                     * to one layer, so the workers write disjoint elements) */
+                    if (query_disp && query_cost)
+                        for (size_t i = 0; i < n; ++i)
+                            if (query_disp[i] == d) query_cost[i] = filtered[i];
                 }
             }
             free(layer); free(filtered);
@@ -642,6 +648,26 @@ int orc_compute_disparity_allcores(const float *left, const float *right, int he
         }
     free(dsi); free(guide); free(mean_guide); free(var_g); free(best_c); free(best_d);
     return rc;
+}
+
+int orc_compute_disparity_allcores(const float *left, const float *right, int height, int width, int dmax,
+                                   int wct_radius, double base_weight, int radius, double eps,
+                                   int32_t *disparity, float *min_cost, int threads) {
+    return compute_disparity_allcores_impl(left, right, height, width, dmax, wct_radius, base_weight, radius, eps,
+                                           disparity, min_cost, NULL, NULL, threads);
+}
+
+/* The same, and in addition the reference's own filtered cost F(y, x, query_disp[y, x]) (stereo.py:150, the value
+ * that stereo.py:167 compares) for a caller-chosen disparity per pixel: what a gap-aware comparison of two
+ * disparity maps needs, without keeping the dmax filtered layers.  query_cost is NaN where the queried disparity
+ * lies outside [0, dmax). */
+int orc_compute_disparity_query(const float *left, const float *right, int height, int width, int dmax,
+                                int wct_radius, double base_weight, int radius, double eps, int32_t *disparity,
+                                float *min_cost, const int32_t *query_disp, float *query_cost, int threads) {
+    if (!query_disp || !query_cost) return ORC_EINVAL;
+    for (size_t i = 0, n = (size_t)height * width; i < n; ++i) query_cost[i] = NAN;
+    return compute_disparity_allcores_impl(left, right, height, width, dmax, wct_radius, base_weight, radius, eps,
+                                           disparity, min_cost, query_disp, query_cost, threads);
 }
 
 int orc_max_threads(void) {

@@ -622,7 +622,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (a.gate_min > 0.f) {
         const bool fast_range = eps_gate_takes_fast(a.gate_eps, a.gate_min, *a.gmax);
         precise = !fast_range;
-        if (precise && !(a.precise != 0 && eps_gate_takes_fast(a.gate_eps, a.gate_low, *a.gmax))) return;
+        // (no lower end, gate_low <= 0: no test -- for a guide whose square overflows float32 the product
+        //  gate_low * inf would be NaN and the comparison false, and no kernel would take the frame)
+        if (precise && !(a.precise != 0 && (a.gate_low <= 0.f || eps_gate_takes_fast(a.gate_eps, a.gate_low, *a.gmax)))) return;
     }
     const int lane = threadIdx.x & 63;
     const int H = a.H, W = a.W;

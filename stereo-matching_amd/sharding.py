@@ -300,13 +300,32 @@ def deal_scenes(sizes: Sequence[int], world: int) -> List[List[int]]:
 
 def run_scenes_parallel(scene_names: Sequence[str], sizes: Sequence[int], world: int, rank: int,
                         run_scene: Callable[[str], Dict[str, float]]) -> Optional[Dict[str, Dict[str, float]]]:
-    """Run this rank's share of the scenes and gather {scene: metrics} on rank 0."""
+    """Run this rank's share of the scenes and gather {scene: metrics} on rank 0 (sorted by scene name, whatever
+    the dealing was); None on the other ranks.
+
+    A scene that raises stops its rank's share; the error texts are exchanged before the gather, so that EVERY rank
+    raises RuntimeError naming the failed scenes -- a rank that raised alone would leave its peers blocked in the
+    gather.  With one rank the scene's own exception propagates, as in the reference's sequential loop
+    (reference stereo.py:722-778)."""
+    plan = deal_scenes(sizes, world)
+    mine: Dict[str, Dict[str, float]] = {}
+    if world == 1:
+        for i in plan[rank]:
+            mine[scene_names[i]] = run_scene(scene_names[i])
+        return {k: mine[k] for k in sorted(mine)}
     import torch.distributed as dist
 
-    plan = deal_scenes(sizes, world)
-    mine = {scene_names[i]: run_scene(scene_names[i]) for i in plan[rank]}
-    if world == 1:
-        return mine
+    failure: Optional[str] = None
+    for i in plan[rank]:
+        try:
+            mine[scene_names[i]] = run_scene(scene_names[i])
+        except Exception as exc:   # noqa: BLE001 -- reported on every rank below
+            failure = f"rank {rank}, scene {scene_names[i]}: {type(exc).__name__}: {exc}"
+            break
+    failures: List[Optional[str]] = [None] * world
+    dist.all_gather_object(failures, failure)
+    if any(failures):
+        raise RuntimeError("scene-parallel batch failed: " + "; ".join(f for f in failures if f))
     gathered: Optional[list] = [None] * world if rank == 0 else None
     dist.gather_object(mine, gathered, dst=0)
     if rank != 0:

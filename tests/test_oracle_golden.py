@@ -49,6 +49,25 @@ def test_guided_pipeline_bit_exact(oracle, name):
     assert np.array_equal(d2, disp) and np.array_equal(c2, cost)
 
 
+def test_query_returns_the_filtered_cost_at_the_queried_disparity(oracle):
+    """oracle.compute_disparity_query against the reference's own filtered layers (golden): the cost it reports for
+    a queried disparity per pixel is that layer's value, bit for bit; out-of-range queries give NaN."""
+    g = load_golden("guided_48x80x16")
+    dmax, r_c, gr, eps = int(g["dmax"]), int(g["wct_radius"]), int(g["guided_radius"]), float(g["guided_eps"])
+    layers = g["guided_layers"]
+    rng = np.random.default_rng(5)
+    query = rng.integers(0, dmax, size=g["left"].shape).astype(np.int32)
+    query[0, :5] = [-1, dmax, dmax + 7, 0, dmax - 1]
+    d, c, fq = oracle.compute_disparity_query(g["left"], g["right"], dmax, query, wct_radius=r_c, radius=gr, eps=eps, threads=3)
+    assert np.array_equal(d, g["disparity"]) and np.array_equal(c, g["min_cost"])
+    inside = (query >= 0) & (query < dmax)
+    want = np.take_along_axis(layers, np.clip(query, 0, dmax - 1)[None], axis=0)[0]
+    assert np.array_equal(fq[inside], want[inside]) and np.all(np.isnan(fq[~inside])) and (~inside).sum() == 3
+    # queried at the winner, it is the minimum itself
+    _, _, fmin = oracle.compute_disparity_query(g["left"], g["right"], dmax, d, wct_radius=r_c, radius=gr, eps=eps)
+    assert np.array_equal(fmin, c)
+
+
 def test_operators_bit_exact(oracle):
     g = load_golden("operators_48x80")
     assert np.array_equal(oracle.integral_image(g["left"]), g["integral_left"])

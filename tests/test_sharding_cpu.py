@@ -168,3 +168,131 @@ def test_shard_ranges_cover_and_scene_dealer():
     assert max(loads) - min(loads) <= max(sizes)
     out = sharding.run_scenes_parallel(["b", "a"], [1, 2], 1, 0, lambda s: {"pbm": float(len(s))})
     assert list(out) == ["a", "b"]
+
+
+# ---- scene-parallel batches (reference stereo.py:722-778 is the sequential loop they replace) ----------------------
+SCENES = {   # scene -> (width, height, ndisp): heterogeneous work, names out of sorted order
+    "Vintage-perfect": (40, 24, 76), "Adirondack-perfect": (36, 25, 29), "Piano-perfect": (35, 24, 26),
+    "Jadeplant-perfect": (33, 25, 64), "Motorcycle-perfect": (37, 25, 27), "Backpack-perfect": (36, 25, 26),
+    "Umbrella-perfect": (37, 25, 25),
+}
+
+
+def _make_fake_dataset(root: str) -> dict:
+    """The dataset layout the batch mode walks: <root>/<scene>/im0.png (only its header is read, to size the work).
+    One listed scene has no folder: it must be skipped, as the reference does (stereo.py:724-727)."""
+    from PIL import Image
+    for scene, (w, h, _) in SCENES.items():
+        os.makedirs(os.path.join(root, scene))
+        Image.fromarray(np.zeros((h, w), np.uint8)).save(os.path.join(root, scene, "im0.png"))
+    ndisp = {scene: nd for scene, (_, _, nd) in SCENES.items()}
+    ndisp["Missing-perfect"] = 50
+    return ndisp
+
+
+def _stub_run_scene(fail_scene=None, log=None):
+    """Stands in for stereo._run_scene: metrics that depend on the scene alone."""
+    def run(args, run_dir, left, right, gt, gt_mask, dmax, **kw):
+        scene = kw["dataset_name"]
+        if log is not None:
+            log.append(scene)
+        if scene == fail_scene:
+            raise ValueError(f"cannot read {scene}")
+        return {"pbm": float(dmax) / 7.0, "rms": float(len(scene)) * 0.37, "bad_threshold": float(args.bad_threshold),
+                "valid_pixel_count": float(dmax * 11)}
+    return run
+
+
+def _batch_args():
+    import stereo
+    return stereo._parse_args(["--all-datasets", "--bad_threshold", "1.0", "--guided_eps", "0.0154"])
+
+
+def _scene_worker(rank: int, world: int, port: int, root: str, run_dir: str, fail_scene) -> None:
+    for p in (PKG_DIR, REPO_ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import json
+    from pathlib import Path
+
+    import torch.distributed as dist
+
+    import stereo
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ndisp = {scene: nd for scene, (_, _, nd) in SCENES.items()}
+        ndisp["Missing-perfect"] = 50
+        ran = []
+        stereo._run_scene = _stub_run_scene(fail_scene, ran)
+        stereo._resolve_scene_inputs = lambda root_, scene, table, override: (Path("l"), Path("r"), Path("g"), Path("m"),
+                                                                              table[scene])
+        status = "ok"
+        try:
+            summary = stereo._run_all_datasets(_batch_args(), Path(root), ndisp, Path(run_dir), world, rank)
+            if (summary is None) != (rank != 0):
+                status = "summary on the wrong rank"
+        except RuntimeError as exc:
+            status = f"raised: {exc}"
+        with open(os.path.join(run_dir, f"rank{rank}.json"), "w") as f:
+            json.dump({"status": status, "ran": ran}, f)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_scene_parallel_batch_over_gloo(world, monkeypatch):
+    """stereo._run_all_datasets on `world` gloo ranks with a stub per-scene function: metrics_summary.json is byte
+    for byte the single-rank file, scenes in sorted order, every scene run exactly once and the load spread over
+    the ranks; a scene that raises makes every rank raise."""
+    import json
+    from pathlib import Path
+
+    import torch.multiprocessing as mp
+
+    import stereo
+
+    with tempfile.TemporaryDirectory() as tmp:
+        root = os.path.join(tmp, "dataset")
+        ndisp = _make_fake_dataset(root)
+        # world 1, in this process
+        single = os.path.join(tmp, "single")
+        os.makedirs(single)
+        monkeypatch.setattr(stereo, "_run_scene", _stub_run_scene())
+        monkeypatch.setattr(stereo, "_resolve_scene_inputs",
+                            lambda root_, scene, table, override: (Path("l"), Path("r"), Path("g"), Path("m"), table[scene]))
+        summary = stereo._run_all_datasets(_batch_args(), Path(root), ndisp, Path(single), 1, 0)
+        assert list(summary["scenes"]) == sorted(SCENES) and summary["scene_count"] == len(SCENES)
+        assert summary["bad_threshold"] == 1.0
+        want = open(os.path.join(single, "metrics_summary.json"), "rb").read()
+        # the same batch on `world` ranks
+        multi = os.path.join(tmp, "multi")
+        os.makedirs(multi)
+        mp.spawn(_scene_worker, args=(world, _free_port(), root, multi, None), nprocs=world, join=True)
+        assert open(os.path.join(multi, "metrics_summary.json"), "rb").read() == want
+        reports = [json.load(open(os.path.join(multi, f"rank{r}.json"))) for r in range(world)]
+        assert all(r["status"] == "ok" for r in reports), reports
+        ran = [s for r in reports for s in r["ran"]]
+        assert sorted(ran) == sorted(SCENES)
+        work = {s: w * h * nd for s, (w, h, nd) in SCENES.items()}
+        loads = [sum(work[s] for s in r["ran"]) for r in reports]
+        assert max(loads) - min(loads) <= max(work.values()) and min(loads) > 0
+        # every scene got its own output folder, on whichever rank ran it
+        assert sorted(d for d in os.listdir(multi) if os.path.isdir(os.path.join(multi, d))) == sorted(SCENES)
+        # one scene raises on the rank that runs it: every rank raises, nobody hangs in the gather
+        failing = os.path.join(tmp, "failing")
+        os.makedirs(failing)
+        mp.spawn(_scene_worker, args=(world, _free_port(), root, failing, "Piano-perfect"), nprocs=world, join=True)
+        reports = [json.load(open(os.path.join(failing, f"rank{r}.json"))) for r in range(world)]
+        assert all(r["status"].startswith("raised:") and "Piano-perfect" in r["status"] for r in reports), reports
+        assert not os.path.exists(os.path.join(failing, "metrics_summary.json"))
+    # with one rank the scene's own exception propagates
+    with tempfile.TemporaryDirectory() as tmp:
+        root = os.path.join(tmp, "dataset")
+        ndisp = _make_fake_dataset(root)
+        monkeypatch.setattr(stereo, "_run_scene", _stub_run_scene("Piano-perfect"))
+        os.makedirs(os.path.join(tmp, "run"))
+        with pytest.raises(ValueError):
+            stereo._run_all_datasets(_batch_args(), Path(root), ndisp, Path(tmp) / "run", 1, 0)
