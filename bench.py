@@ -48,7 +48,7 @@ FILTERS = {"guided": "FILTER_GUIDED", "median": "FILTER_MEDIAN_U8Q", "gaussian":
            "bilateral": "FILTER_BILATERAL"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
 # per-launch counter averages of a `rocprofv3 --pmc` run of this same command (tools/pmc_passes.sh)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pair_pmc_per_launch.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "pair_pmc_per_launch.json")
 DOMINANT_KERNEL = "fused_guided_pair_kernel"
 
 
@@ -117,8 +117,8 @@ def host_cpu_model() -> str:
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400, help="timed steps (the default makes the timed region last about a second)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="motorcycle")
     ap.add_argument("--filter", choices=sorted(FILTERS), default="guided",
                     help="aggregation filter (median = the reference's default uint8-quantised method, radius 3; "
@@ -223,7 +223,10 @@ def main() -> None:
         desc = desc.replace("eps=0.0154", f"eps={args.eps}")
         args.no_cpu_baseline = True   # (the CPU leg is defined on the benchmark's own parameters)
     ws_bytes = ctypes.c_size_t(0)
-    _native.check(lib.stereo_fused_workspace_bytes(H, W, params, ctypes.byref(ws_bytes)))
+    if two_call:   # (room for the volume's 16-bit cost codes behind the fused workspace)
+        _native.check(lib.stereo_aggregate_workspace_bytes(H, W, D, params, ctypes.byref(ws_bytes)))
+    else:
+        _native.check(lib.stereo_fused_workspace_bytes(H, W, params, ctypes.byref(ws_bytes)))
     workspace = torch.empty(ws_bytes.value, dtype=torch.uint8, device=dev)
     n = H * W
     d_begin, d_end = sharding.shard_range(D, world, rank)
@@ -258,6 +261,23 @@ def main() -> None:
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             _native.check(lib.stereo_aggregate_wta_dev(dsi.data_ptr(), left.data_ptr(), H, W, D, params, 0, D,
                                                        workspace.data_ptr(), ws_bytes.value, frame_keys.data_ptr(), stream))
+
+        # the aggregation's two kernels on their own (timed separately below): the encoder that streams the volume
+        # once into 16-bit cost codes, one layer per disparity, and the two-column kernel on the codes
+        codes_bytes = ctypes.c_size_t(0)
+        _native.check(lib.stereo_cost_codes_bytes(H, W, D, ctypes.byref(codes_bytes)))
+        codes = torch.empty(codes_bytes.value, dtype=torch.uint8, device=dev)
+
+        def encode() -> None:
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _native.check(lib.stereo_encode_cost_volume_dev(dsi.data_ptr(), H, W, D, 0, D, codes.data_ptr(), codes_bytes.value,
+                                                            stream))
+
+        def aggregate_codes() -> None:
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _native.check(lib.stereo_aggregate_wta_codes_dev(codes.data_ptr(), dsi.data_ptr(), left.data_ptr(), H, W, D, params,
+                                                             0, D, workspace.data_ptr(), ws_bytes.value, frame_keys.data_ptr(),
+                                                             stream))
 
         def step() -> None:
             cost_volume()
@@ -303,7 +323,7 @@ def main() -> None:
     if two_call:
         # each of the two kernels on its own, events on the launch stream
         timed = {}
-        for name, fn in (("dsi_kernel", cost_volume), ("fused_guided_kernel<SRC_DSI>", aggregate)):
+        for name, fn in (("dsi_kernel", cost_volume), ("cost_encode_kernel", encode), ("fused_guided_pair_kernel<codes>", aggregate_codes)):
             fn()
             torch.cuda.synchronize()
             _native.check(lib.stereo_profile_begin(args.steps))
@@ -312,15 +332,35 @@ def main() -> None:
             torch.cuda.synchronize()
             _native.check(lib.stereo_profile_end(ctypes.byref(kernel_ms), ctypes.byref(launches)))
             timed[name] = kernel_ms.value / max(launches.value, 1)
-        kernel_step_ms = timed["fused_guided_kernel<SRC_DSI>"]
+        kernel_step_ms = timed["cost_encode_kernel"] + timed["fused_guided_pair_kernel<codes>"]
         vol_bytes = n * D * 4
         two_call_info = {
             "cost_volume_bytes": vol_bytes,
             "dsi_kernel_ms": round(timed["dsi_kernel"], 4),
             "dsi_kernel_write_gbs": round(vol_bytes / (timed["dsi_kernel"] * 1e-3) / 1e9, 1),
-            "aggregate_kernel_ms": round(kernel_step_ms, 4),
-            "aggregate_kernel_read_gbs": round(vol_bytes / (kernel_step_ms * 1e-3) / 1e9, 1),
+            "encode_kernel_ms": round(timed["cost_encode_kernel"], 4),
+            "encode_kernel_read_plus_write_gbs": round(vol_bytes * 1.5 / (timed["cost_encode_kernel"] * 1e-3) / 1e9, 1),
+            "search_kernel_ms": round(timed["fused_guided_pair_kernel<codes>"], 4),
+            "aggregate_ms": round(kernel_step_ms, 4),
+            "aggregate_volume_read_gbs": round(vol_bytes / (kernel_step_ms * 1e-3) / 1e9, 1),
         }
+    # the all-float64 ("precise") variant of the dominant kernel on the same frame, a few untimed steps: the timed
+    # variant mixes precisions (see "dtype"), and the line carries both figures
+    precise_ms = None
+    if world == 1 and not use_dist and not two_call and args.filter == "guided" and n_bands == 1:
+        _native.check(lib.stereo_debug_force_general_kernel(3))
+        try:
+            step()
+            torch.cuda.synchronize()
+            _native.check(lib.stereo_profile_begin(5))
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            pk, pl = ctypes.c_double(0.0), ctypes.c_int(0)
+            _native.check(lib.stereo_profile_end(ctypes.byref(pk), ctypes.byref(pl)))
+            precise_ms = pk.value / max(pl.value, 1)
+        finally:
+            _native.check(lib.stereo_debug_force_general_kernel(0))
     if use_dist:
         t = torch.tensor([elapsed, kernel_step_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -385,16 +425,27 @@ def main() -> None:
         traffic = measured_hbm_traffic(args.workload, library_version) if world == 1 and args.filter == "guided" and not two_call else None
         lds_rate, valu_busy = counter_ratios(args.workload, library_version) if traffic is not None else (None, None)
         if two_call:
-            kernel_name = "fused_guided_kernel<SRC_DSI>"
-            note = ("two-call path: the float32 cost volume is written by dsi_kernel and read back by the aggregation "
-                    "kernel, so the bytes are real HBM bytes (4 B per pixel-disparity read + 12 B per pixel); see two_call")
+            kernel_name = "cost_encode_kernel + fused_guided_pair_kernel<codes>"
+            note = ("two-call path: the float32 cost volume is written by dsi_kernel and read back by the aggregation, so "
+                    "the algorithmic bytes are real HBM bytes (4 B per pixel-disparity read + 12 B per pixel); the "
+                    "aggregation is two kernels -- the encoder streams the volume once into 16-bit cost codes, one layer "
+                    "per disparity (reads 4 B, writes 2 B per pixel-disparity), the two-column kernel filters the codes "
+                    "(reads 2 B per pixel-disparity plus tile halos) -- and kernel_ms is their sum; see two_call")
         else:
             kernel_name = DOMINANT_KERNEL if args.filter == "guided" else "fused_filter_kernel"
-            note = ("DSI-equivalent % of HBM peak: 8 B per pixel-disparity (a float32 cost volume written once "
-                    "and read once, which the fused kernel never materialises) + 16 B per pixel; traffic = "
-                    "measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate run of this "
-                    "command on this build of the library, null when no such run is committed); the kernel is "
-                    "bound by vector-instruction issue (lane-shift and float64 ops), not by HBM")
+            note = ("achieved/frac are DSI-EQUIVALENT figures: 8 B per pixel-disparity (a float32 cost volume written "
+                    "once and read once, which the fused kernel never materialises) + 16 B per pixel, over the kernel "
+                    "time, against the HBM peak -- the accounting the benchmark's metric defines, not the bytes moved.  "
+                    "What limits the kernel is vector-instruction issue (binding_resource / valu_busy); the bytes it "
+                    "really moves are traffic (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, separate run of this "
+                    "command on this build of the library, null when no such run is committed) = actual_hbm_frac of "
+                    "the HBM peak.  frac_step is the same accounting over the whole step (every kernel of it)")
+        if args.filter != "guided":
+            dtype_label = "u8" if args.filter == "median" else "f32"
+        elif two_call or args.eps >= 8e-3:
+            dtype_label = "mixed f64/f32 (exact int32 window sums of the costs, float64 a/b and their vertical sums, float32 second box stage)"
+        else:
+            dtype_label = "f64 (exact int32 window sums of the costs, float64 everywhere else)"
         out = {
             "metric": f"MDE/s (10^6 pixel-disparity evals/s), {'two-call' if two_call else 'fused'} WCT+{args.filter}+WTA",
             "value": None if error else round(evals * args.steps / elapsed / 1e6, 1),
@@ -406,7 +457,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": dtype_label,
             "data": "synthetic",
             "config": {"workload": desc, "height": H, "width": W, "dmax": D,
                        "parallelism": "single GPU" if world == 1 else f"disparity range sharded over {world} GPUs, "
@@ -414,7 +465,16 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_step": round(H * W * ((4 * D + 12) if two_call else (8 * D + 16)) / (ms_per_step * 1e-3) / 1e9
+                                   / HBM_PEAK_GBS, 4) if world == 1 else None,
+                "dsi_equivalent": not two_call,
+                "binding_resource": "hbm" if two_call else "vector-instruction issue (VALU)",
                 "traffic": traffic,
+                "actual_hbm_frac": round(traffic / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                if traffic is not None and kernel_avg_ms > 0 else None,
+                "precise_variant_kernel_ms": round(precise_ms, 4) if precise_ms is not None else None,
+                "precise_variant_frac": round(alg_bytes / (precise_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                if precise_ms else None,
                 "kernel": kernel_name, "kernel_ms": round(kernel_avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "compulsory_frac": round(H * W * 16 / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)

@@ -105,10 +105,11 @@ int stereo_bilateral_filter_host(const float *image, int height, int width, doub
 int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dtype, int height, int width,
                               int dmax, const StereoParams *params, int d_begin, int d_end,
                               int32_t *out_disparity, float *out_min_cost);
-/* compute_disparity (stereo.py:177-245).  float32 / uint8 images with the guided filter
- * (radius <= 4) take the fused kernel: the cost volume is never materialised.  Other
- * combinations build the cost layers on the device and filter them one at a time.
- * Disparities d in [d_begin, d_end) are searched. */
+/* compute_disparity (stereo.py:177-245).  float32 / uint8 images take a fused kernel -- the cost volume is never
+ * materialised -- for the guided filter (radius 1..8), the uint8-quantised median, the Gaussian and the bilateral
+ * filter (window radius 1..8) and, for census weights whose sums are exact in float32, the exact median
+ * (radius 1..8).  Other combinations (float64 images, larger windows, the exact median with other weights) build
+ * the cost layers on the device and filter them one at a time.  Disparities d in [d_begin, d_end) are searched. */
 int stereo_compute_disparity_host(const void *left, const void *right, int dtype, int height, int width,
                                   int dmax, const StereoParams *params, int d_begin, int d_end,
                                   int32_t *out_disparity, float *out_min_cost);
@@ -133,9 +134,10 @@ int stereo_fused_workspace_bytes(int height, int width, const StereoParams *para
  * packed key per pixel: (order-preserving uint32 image of the float32 min cost) << 32 | d, so
  * that an unsigned 64-bit MIN over keys of different disparity shards is the reference's
  * "lowest cost, ties to the lowest disparity" rule (stereo.py:167-170).
- * Covers the guided filter (radius 1..8), the uint8-quantised median (radius 1..4) and the
- * Gaussian / bilateral filters (ceil(3 sigma) <= 4); other parameters return STEREO_EUNSUPPORTED
- * (the host entry point falls back to the layer-at-a-time path for them). */
+ * Covers the guided filter (radius 1..8), the uint8-quantised median (radius 1..8), the exact median
+ * (radius 1..8, census weights whose sums are exact in float32) and the Gaussian / bilateral filters
+ * (max(ceil(3 sigma), 1) <= 8); other parameters return STEREO_EUNSUPPORTED (the host entry point falls back to
+ * the layer-at-a-time path for them). */
 int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int height, int width, int dmax,
                                  const StereoParams *params, int d_begin, int d_end, void *d_workspace,
                                  size_t workspace_bytes, uint64_t *d_keys, void *stream);
@@ -150,6 +152,26 @@ int stereo_wct_cost_volume_dev(const float *d_left, const float *d_right, int he
 int stereo_aggregate_wta_dev(const float *d_dsi, const float *d_guide, int height, int width, int dmax,
                              const StereoParams *params, int d_begin, int d_end, void *d_workspace,
                              size_t workspace_bytes, uint64_t *d_keys, void *stream);
+/* Workspace of stereo_aggregate_wta_dev that lets it run at memory speed: the fused workspace plus room for the
+ * volume's "cost codes".  The volume's layout (census.py:250, D innermost) puts a pixel's disparities side by side,
+ * the per-layer filter of stereo.py:145-166 wants a layer's pixels side by side; with this workspace the entry
+ * point first streams the volume once through an encoder that transposes it into one [H][W] layer per disparity of
+ * 16-bit whole numbers of the volume's cost unit (census costs are multiples of a power of two, census.py:58-62),
+ * and the two-column kernel of the single-call path filters those.  A volume whose costs are not such multiples (or
+ * negative, not finite, 2^16 units and above), and guided radii 5..8, are served by the general kernel reading the
+ * float32 volume in place -- as is every volume when the workspace only has stereo_fused_workspace_bytes. */
+int stereo_aggregate_workspace_bytes(int height, int width, int dmax, const StereoParams *params, size_t *bytes);
+/* The two steps of stereo_aggregate_wta_dev on their own, for callers that aggregate one volume several times
+ * (stereo.aggregate_and_wta with different filter parameters on the same dsi, README:144-175): encode layers
+ * [d_begin, d_end) of d_dsi[H][W][dmax] once into a buffer of stereo_cost_codes_bytes(H, W, d_end - d_begin), then
+ * aggregate from the codes (the volume is still passed: it is what the general kernel reads if the codes turn out
+ * unusable).  d_begin / d_end of the two calls must agree. */
+int stereo_cost_codes_bytes(int height, int width, int n_disparities, size_t *bytes);
+int stereo_encode_cost_volume_dev(const float *d_dsi, int height, int width, int dmax, int d_begin, int d_end,
+                                  void *d_codes, size_t codes_bytes, void *stream);
+int stereo_aggregate_wta_codes_dev(const void *d_codes, const float *d_dsi, const float *d_guide, int height, int width,
+                                   int dmax, const StereoParams *params, int d_begin, int d_end, void *d_workspace,
+                                   size_t workspace_bytes, uint64_t *d_keys, void *stream);
 /* stereo_compute_disparity_dev without the workspace argument.  No counterpart in the reference; it is for
  * callers that cannot allocate device memory or carry a workspace: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  The scratch (census words, guide statistics, per-layer ranges) is a
@@ -210,9 +232,9 @@ int stereo_hip_release_cache(void);
  * uses, so the variants can be compared on the same input.  0 = the best one that applies
  * (default), 1 = the general kernel (float64 sums exchanged through LDS), 2 = the fast kernel
  * with one image column per lane (the default fast kernel gives every lane two columns), 3 = the
- * two-column kernel's precise variant, float64 where the fast one has float32 (the default for eps between 1e-4
- * and 8e-3 times max(1, max|guide|^2)).  Mode 1 also makes the fused uint8-median kernel take its plain
- * bisection instead of the bit-sliced count. */
+ * two-column kernel's precise variant, float64 where the fast one has float32 (the default for every eps below
+ * 8e-3 times max(1, max|guide|^2), guided radius <= 4).  Mode 1 also makes the fused uint8-median kernel take its
+ * plain bisection instead of the bit-sliced count. */
 int stereo_debug_force_general_kernel(int mode);
 
 /* Timing of the dominant (fused) kernel with HIP events recorded on the launch stream, for

@@ -62,6 +62,10 @@ _SIGNATURES = {
     "stereo_wct_cost_volume_dev": [_VP, _VP, _I, _I, _I, _I, _D, _VP, _SZ, _VP, _VP],
     "stereo_aggregate_wta_dev": [_VP, _VP, _I, _I, _I, _PP, _I, _I, _VP, _SZ, _VP, _VP],
     "stereo_compute_disparity_dev": [_VP, _VP, _I, _I, _I, _PP, _I, _I, _VP, _SZ, _VP, _VP],
+    "stereo_aggregate_workspace_bytes": [_I, _I, _I, _PP, ctypes.POINTER(ctypes.c_size_t)],
+    "stereo_cost_codes_bytes": [_I, _I, _I, ctypes.POINTER(ctypes.c_size_t)],
+    "stereo_encode_cost_volume_dev": [_VP, _I, _I, _I, _I, _I, _VP, _SZ, _VP],
+    "stereo_aggregate_wta_codes_dev": [_VP, _VP, _VP, _I, _I, _I, _PP, _I, _I, _VP, _SZ, _VP, _VP],
     "stereo_progress_plan": [_I, _I, _PP, _I, _VP, ctypes.POINTER(ctypes.c_int)],
     "stereo_compute_disparity_progress_dev": [_VP, _VP, _I, _I, _I, _PP, _I, _I, _VP, _SZ, _VP, _I, _VP, ctypes.c_uint32,
                                               _VP],

@@ -18,7 +18,11 @@ pids=()
 for src in "${SRCS[@]}"; do
   obj="$HERE/csrc/obj/$(basename "${src%.hip}").o"
   OBJS+=("$obj")
-  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$HERE/csrc/common.hpp" -nt "$obj" || "$HERE/csrc/census_dev.hpp" -nt "$obj" || "$HERE/csrc/fast_common.hpp" -nt "$obj" || "$HERE/../include/stereo_hip.h" -nt "$obj" || "$HERE/build.sh" -nt "$obj" ]]; then
+  stale=0
+  for dep in "$src" "$HERE"/csrc/*.hpp "$HERE/../include/stereo_hip.h" "$HERE/build.sh"; do
+    [[ "$dep" -nt "$obj" ]] && stale=1
+  done
+  if [[ ! -f "$obj" || $stale -eq 1 ]]; then
     # The fused kernels keep two independent columns per lane in scalar registers: packing them into
     # v_pk_* instructions costs register shuffles and issues no faster on gfx950.
     file_flags=""
@@ -28,7 +32,7 @@ for src in "${SRCS[@]}"; do
       #  operations 0.9 % faster than the default, the one that favours instruction-level parallelism 0.5 %;
       #  relaxed occupancy another 0.55 %.  The post-RA scheduler stays as it is: without it + 5.5 %, bottom-up
       #  + 2.5 %, bidirectional + 6 %)
-      guided_pair.hip) file_flags="-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-memory-clause -mllvm -amdgpu-schedule-relaxed-occupancy=true" ;;
+      guided_pair.hip|guided_pair_codes.hip) file_flags="-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-memory-clause -mllvm -amdgpu-schedule-relaxed-occupancy=true" ;;
       guided_fast.hip) file_flags="-fno-slp-vectorize" ;;
       api.hip) file_flags="-DSTEREO_BUILD_ID=\"$BUILD_ID\"" ;;
     esac

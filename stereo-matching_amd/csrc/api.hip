@@ -566,8 +566,81 @@ int stereo_wct_cost_volume_dev(const float *d_left, const float *d_right, int H,
     return prof.end();
 }
 
-int stereo_aggregate_wta_dev(const float *d_dsi, const float *d_guide, int H, int W, int dmax, const StereoParams *p,
-                             int d_begin, int d_end, void *ws, size_t ws_bytes, uint64_t *d_keys, void *stream) {
+// Cost codes of a volume: a header of PAIR_CODE_STATS_WORDS device words (256 bytes reserved), then one [H][W] layer
+// of 16-bit codes per disparity of the encoded range.
+constexpr size_t CODES_HEADER_BYTES = 256;
+constexpr int CODES_MAX_DISPARITIES = 639;   // per encoding: a group of 128 pixels x all disparities fits the LDS
+static bool aggregate_from_codes_applies(const StereoParams *p, int n_disp) {
+    return p->filter_kind == STEREO_FILTER_GUIDED && p->guided_radius >= 1 && p->guided_radius <= 4 &&
+           n_disp <= CODES_MAX_DISPARITIES;
+}
+
+int stereo_cost_codes_bytes(int H, int W, int n_disp, size_t *bytes) {
+    if (!bytes) { set_error("null pointer"); return STEREO_EINVAL; }
+    SHP_TRY(check_image_dims(H, W));
+    if (n_disp < 0) { set_error("negative disparity count"); return STEREO_EINVAL; }
+    *bytes = CODES_HEADER_BYTES + cost_codes_bytes(H, W, n_disp);
+    return STEREO_OK;
+}
+
+int stereo_encode_cost_volume_dev(const float *d_dsi, int H, int W, int dmax, int d_begin, int d_end, void *d_codes,
+                                  size_t codes_bytes, void *stream) {
+    if (!d_dsi || !d_codes) { set_error("null pointer"); return STEREO_EINVAL; }
+    SHP_TRY(check_image_dims(H, W));
+    if (dmax <= 0) { set_error("dsi must have at least one disparity layer"); return STEREO_EINVAL; }
+    if (d_begin < 0 || d_end > dmax || d_begin > d_end) { set_error("bad disparity range"); return STEREO_EINVAL; }
+    const size_t need = CODES_HEADER_BYTES + cost_codes_bytes(H, W, d_end - d_begin);
+    if (codes_bytes < need) { set_error("cost-code buffer too small: %zu < %zu", codes_bytes, need); return STEREO_EINVAL; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned char *base = static_cast<unsigned char *>(d_codes);
+    ProfScope prof(s);
+    SHP_TRY(prof.begin());
+    SHP_TRY(launch_encode_cost_codes(d_dsi, H, W, dmax, d_begin, d_end,
+                                     reinterpret_cast<uint16_t *>(base + CODES_HEADER_BYTES),
+                                     reinterpret_cast<uint32_t *>(base), s));
+    return prof.end();
+}
+
+// guide statistics + the kernels of aggregate_and_wta with the guided filter; d_codes (optional) holds the codes of
+// layers [d_begin, d_end) of d_dsi
+static int aggregate_guided_dev(const float *d_dsi, const void *d_codes, const float *d_guide, int H, int W, int dmax,
+                                const StereoParams *p, int d_begin, int d_end, void *ws, size_t ws_bytes,
+                                uint64_t *d_keys, hipStream_t s) {
+    FusedWs L = fused_ws_layout(H, W, p->wct_radius);
+    if (ws_bytes < L.total) { set_error("workspace too small: %zu < %zu", ws_bytes, L.total); return STEREO_EINVAL; }
+    unsigned char *base = static_cast<unsigned char *>(ws);
+    double *mean = reinterpret_cast<double *>(base + L.off_mean);
+    double *invden = reinterpret_cast<double *>(base + L.off_invden);
+    float *gmax = reinterpret_cast<float *>(base + L.off_gmax);
+    SHP_TRY(launch_guide_stats(d_guide, STEREO_DT_F32, H, W, p->guided_radius, p->guided_eps, mean, invden, gmax, s));
+    if (d_begin == d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
+    ProfScope prof(s);
+    SHP_TRY(prof.begin());
+    const uint32_t *code_stats = nullptr;
+    if (d_codes && aggregate_from_codes_applies(p, d_end - d_begin) && g_force_kernel != 1) {
+        // The two-column kernel on the cost codes (its fast or its precise variant by eps against the guide's
+        // range, chosen on the device), then the general kernel with the opposite test on the encoder's words:
+        // it runs only for a volume whose costs are not whole numbers of a common unit, or too large to pack.
+        const unsigned char *cb = static_cast<const unsigned char *>(d_codes);
+        code_stats = reinterpret_cast<const uint32_t *>(cb);
+        CensusCfg cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.exact = 1; cfg.unit = 1.f; cfg.large = 1.f;
+        const int slices = fused_pair_slices(H, W, p->guided_radius, false, d_end - d_begin);
+        if (slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
+        const bool forced_precise = g_force_kernel == 3;
+        SHP_TRY(launch_fused_guided_pair(nullptr, nullptr, cfg, d_guide, mean, invden, gmax, H, W, dmax, p->guided_radius,
+                                         d_begin, d_end, slices, d_keys, nullptr, s, nullptr, (float)p->guided_eps,
+                                         forced_precise ? 0.f : (float)FAST_KERNEL_MIN_EPS, true, 0.f,
+                                         reinterpret_cast<const uint16_t *>(cb + CODES_HEADER_BYTES), code_stats, d_begin));
+    }
+    SHP_TRY(launch_fused_guided(nullptr, nullptr, nullptr, d_dsi, d_guide, STEREO_DT_F32, mean, invden, H, W, dmax,
+                                p->guided_radius, d_begin, d_end, d_keys, nullptr, 0, s, nullptr, 0.f, 0.f, code_stats));
+    return prof.end();
+}
+
+static int check_aggregate_args(const float *d_dsi, const float *d_guide, int H, int W, int dmax, const StereoParams *p,
+                                int d_begin, int d_end, void *ws, uint64_t *d_keys) {
     if (!d_dsi || !d_guide || !p || !ws || !d_keys) { set_error("null pointer"); return STEREO_EINVAL; }
     SHP_TRY(check_params(p));
     SHP_TRY(check_image_dims(H, W));
@@ -577,20 +650,42 @@ int stereo_aggregate_wta_dev(const float *d_dsi, const float *d_guide, int H, in
         set_error("the device entry point aggregates with the guided filter, radius 1..8");
         return STEREO_EUNSUPPORTED;
     }
-    FusedWs L = fused_ws_layout(H, W, p->wct_radius);
-    if (ws_bytes < L.total) { set_error("workspace too small: %zu < %zu", ws_bytes, L.total); return STEREO_EINVAL; }
+    return STEREO_OK;
+}
+
+int stereo_aggregate_workspace_bytes(int H, int W, int dmax, const StereoParams *p, size_t *bytes) {
+    if (!p || !bytes) { set_error("NULL argument"); return STEREO_EINVAL; }
+    SHP_TRY(check_image_dims(H, W));
+    if (dmax <= 0) { set_error("dsi must have at least one disparity layer"); return STEREO_EINVAL; }
+    size_t total = align_up(fused_ws_layout(H, W, p->wct_radius).total, 256);
+    if (aggregate_from_codes_applies(p, 0)) total += CODES_HEADER_BYTES + cost_codes_bytes(H, W, dmax);
+    *bytes = total;
+    return STEREO_OK;
+}
+
+int stereo_aggregate_wta_dev(const float *d_dsi, const float *d_guide, int H, int W, int dmax, const StereoParams *p,
+                             int d_begin, int d_end, void *ws, size_t ws_bytes, uint64_t *d_keys, void *stream) {
+    SHP_TRY(check_aggregate_args(d_dsi, d_guide, H, W, dmax, p, d_begin, d_end, ws, d_keys));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    unsigned char *base = static_cast<unsigned char *>(ws);
-    double *mean = reinterpret_cast<double *>(base + L.off_mean);
-    double *invden = reinterpret_cast<double *>(base + L.off_invden);
-    SHP_TRY(launch_guide_stats(d_guide, STEREO_DT_F32, H, W, p->guided_radius, p->guided_eps, mean, invden,
-                               base + L.off_gmax, s));
-    if (d_begin == d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
-    ProfScope prof(s);
-    SHP_TRY(prof.begin());
-    SHP_TRY(launch_fused_guided(nullptr, nullptr, nullptr, d_dsi, d_guide, STEREO_DT_F32, mean, invden, H, W, dmax,
-                                p->guided_radius, d_begin, d_end, d_keys, nullptr, 0, s));
-    return prof.end();
+    // a workspace of stereo_aggregate_workspace_bytes holds the cost codes behind the fused workspace; a smaller
+    // one (stereo_fused_workspace_bytes) makes the general kernel read the volume in place
+    const size_t fused_total = align_up(fused_ws_layout(H, W, p->wct_radius).total, 256);
+    const size_t codes_total = CODES_HEADER_BYTES + cost_codes_bytes(H, W, d_end - d_begin);
+    void *codes = nullptr;
+    if (aggregate_from_codes_applies(p, d_end - d_begin) && d_begin < d_end && ws_bytes >= fused_total + codes_total) {
+        codes = static_cast<unsigned char *>(ws) + fused_total;
+        SHP_TRY(stereo_encode_cost_volume_dev(d_dsi, H, W, dmax, d_begin, d_end, codes, codes_total, stream));
+    }
+    return aggregate_guided_dev(d_dsi, codes, d_guide, H, W, dmax, p, d_begin, d_end, ws, ws_bytes, d_keys, s);
+}
+
+int stereo_aggregate_wta_codes_dev(const void *d_codes, const float *d_dsi, const float *d_guide, int H, int W, int dmax,
+                                   const StereoParams *p, int d_begin, int d_end, void *ws, size_t ws_bytes,
+                                   uint64_t *d_keys, void *stream) {
+    if (!d_codes) { set_error("null pointer"); return STEREO_EINVAL; }
+    SHP_TRY(check_aggregate_args(d_dsi, d_guide, H, W, dmax, p, d_begin, d_end, ws, d_keys));
+    return aggregate_guided_dev(d_dsi, d_codes, d_guide, H, W, dmax, p, d_begin, d_end, ws, ws_bytes, d_keys,
+                                static_cast<hipStream_t>(stream));
 }
 
 int stereo_compute_disparity_noalloc_dev(const float *d_left, const float *d_right, int H, int W, int dmax,
@@ -921,7 +1016,24 @@ int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dty
         SHP_HIP(hipMemcpy(&h, flag.p, 4, hipMemcpyDeviceToHost));
         if (h) fused_guided = false;
     }
-    if (fused_guided) {
+    DevBuf ws, codes;
+    size_t gmax_off = 0;
+    if (fused_guided && guide_dtype == STEREO_DT_F32) {
+        // float32 guide: the device path of the two-call API (cost codes + the two-column kernel where they apply)
+        const FusedWs L = fused_ws_layout(H, W, p->wct_radius);
+        gmax_off = L.off_gmax;
+        SHP_TRY(ws.alloc(L.total));
+        void *codes_p = nullptr;
+        if (aggregate_from_codes_applies(p, d_end - d_begin) && d_begin < d_end) {
+            const size_t cbytes = CODES_HEADER_BYTES + cost_codes_bytes(H, W, d_end - d_begin);
+            SHP_TRY(codes.alloc(cbytes));
+            codes_p = codes.p;
+            SHP_TRY(stereo_encode_cost_volume_dev(ddsi.as<float>(), H, W, dmax, d_begin, d_end, codes_p, cbytes, nullptr));
+        }
+        SHP_TRY(aggregate_guided_dev(ddsi.as<float>(), codes_p, dg.as<float>(), H, W, dmax, p, d_begin, d_end, ws.p, L.total,
+                                     keys.as<uint64_t>(), nullptr));
+        check_guide = d_begin < d_end;
+    } else if (fused_guided) {
         SHP_TRY(mean.alloc(n * 8)); SHP_TRY(invden.alloc(n * 8)); SHP_TRY(gmax.alloc(8));
         SHP_TRY(launch_guide_stats(dg.p, guide_dtype, H, W, p->guided_radius, p->guided_eps, mean.as<double>(),
                                    invden.as<double>(), gmax.p, nullptr));
@@ -941,7 +1053,7 @@ int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dty
     SHP_TRY(finish_keys_to_host(keys.as<uint64_t>(), n, out_disp, out_cost));
     if (check_guide) {
         bool finite = true;
-        SHP_TRY(guide_is_finite(gmax.p, &finite));
+        SHP_TRY(guide_is_finite(ws.p ? static_cast<const unsigned char *>(ws.p) + gmax_off : gmax.p, &finite));
         if (!finite) poison_disparity(guide, guide_dtype, H, W, p->guided_radius, out_disp, out_cost);
     }
     return STEREO_OK;

@@ -132,7 +132,8 @@ int launch_fused_guided(const void *d_lw, const void *d_rw, const CensusCfg *cfg
                         const void *d_guide, int guide_dtype, const double *d_mean, const double *d_invden,
                         int H, int W, int dmax, int guided_radius, int d_begin, int d_end, uint64_t *d_keys,
                         float *d_q_out, int atomic_out, hipStream_t s,
-                        const float *gate_gmax = nullptr, float gate_eps = 0.f, float gate_min = 0.f);
+                        const float *gate_gmax = nullptr, float gate_eps = 0.f, float gate_min = 0.f,
+                        const uint32_t *gate_code_stats = nullptr);
 
 
 // fast fused kernel (guided_fast.hip): exact census weights, float32 guide, guided radius <= 4
@@ -150,7 +151,14 @@ int launch_fused_guided_pair(const void *d_lw, const void *d_rw, const CensusCfg
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,
                              float *d_q_out, hipStream_t s, const BandProgress *progress = nullptr,
-                             float gate_eps = 0.f, float gate_min = 0.f, bool precise = false, float gate_low = 0.f);
+                             float gate_eps = 0.f, float gate_min = 0.f, bool precise = false, float gate_low = 0.f,
+                             const uint16_t *d_codes = nullptr, const uint32_t *d_code_stats = nullptr, int code_d0 = 0);
+// Cost codes of a caller-supplied volume (guided_pair_codes.hip): layers [d_begin, d_end) of dsi[H*W][D] as 16-bit
+// whole numbers of the volume's cost unit, one [H*W] layer per disparity, and the words that tell the kernels
+// reading them whether they may (PAIR_CODE_STATS_WORDS uint32 at d_stats).
+size_t cost_codes_bytes(int H, int W, int n_disp);
+int launch_encode_cost_codes(const float *d_dsi, int H, int W, int D, int d_begin, int d_end, uint16_t *d_codes,
+                             uint32_t *d_stats, hipStream_t s);
 int launch_progress_finish(uint32_t *words, int n_bands, uint32_t epoch, hipStream_t s);
 int launch_progress_wait(const uint32_t *words, int band, uint32_t epoch, hipStream_t s);
 bool fused_fast_supported(const CensusCfg &cfg, int guided_radius);

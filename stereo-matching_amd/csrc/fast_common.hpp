@@ -41,7 +41,42 @@ struct FastArgs {
     float gate_low;         // two-column kernel, precise variant: lower end of its eps range (same scaling)
     int precise;            // two-column kernel: with a test, the precise variant (float64 second stage) may take
                             // the frame below the fast range; without one, it is the variant that runs
+    // Two-column kernel on a caller-supplied cost volume: the costs as 16-bit codes (whole numbers of the cost
+    // unit) in the layout of pair_code_index below, for code_dn disparities from code_d0 on, and the encoder's
+    // device words (see pair_codes_accepted).  nullptr: costs from the census words.
+    const uint16_t *codes;
+    const uint32_t *code_stats;
+    int code_d0, code_dn;
 };
+
+// Layout of the cost codes: [row y][group g of 128 columns][disparity][128 columns].  All disparities of 128
+// neighbouring pixels lie side by side: the encoder, which reads the volume pixel by pixel (disparities innermost,
+// as the reference lays it out), writes each such block as ONE contiguous piece, and the kernel that filters
+// layer by layer reads 256-byte rows of it.  The last group of a row is padded to 128 columns.
+constexpr int PAIR_CODE_GROUP = 128;
+__host__ __device__ inline int pair_code_groups(int W) { return (W + PAIR_CODE_GROUP - 1) / PAIR_CODE_GROUP; }
+__host__ __device__ inline size_t pair_code_index(int y, int x, int d, int W, int dn) {
+    return (((size_t)y * pair_code_groups(W) + (size_t)(x / PAIR_CODE_GROUP)) * (size_t)dn + (size_t)d) * PAIR_CODE_GROUP +
+           (size_t)(x % PAIR_CODE_GROUP);
+}
+
+// Words the cost-code encoder leaves for the kernels that read the codes:
+//   [0] s: the cost unit is 2^(s - PAIR_CODE_FRACTION_BITS)   [1] largest code   [2] non-zero: some cost of the volume
+//   is not a whole, non-negative number of units below 2^16 (or not finite): the codes are unusable
+//   [3] (encoder's scratch) OR of the sampled costs in units of 2^-PAIR_CODE_FRACTION_BITS   [4] sample found an unusable cost
+constexpr int PAIR_CODE_FRACTION_BITS = 4;
+constexpr int PAIR_CODE_STATS_WORDS = 8;
+#ifndef PAIR_CODES_ROWS_AHEAD
+#define PAIR_CODES_ROWS_AHEAD 3   // rows the two-column kernel requests its codes ahead (5, 8, 12, 16 measured: no faster)
+#endif
+
+// Whether the two-column kernel serves the encoded volume at guided radius rg: usable codes, and the window sums
+// of (rg + 1) lanes x (2 rg + 1) rows of two packed 16-bit halves cannot overflow.  The general kernel runs with
+// the opposite test.
+__host__ __device__ inline uint32_t pair_code_limit(int rg) { return 65535u / (uint32_t)((rg + 1) * (2 * rg + 1)); }
+__device__ __forceinline__ bool pair_codes_accepted(const uint32_t *stats, int rg) {
+    return stats[2] == 0u && stats[1] <= pair_code_limit(rg);
+}
 
 __device__ __forceinline__ bool eps_gate_takes_fast(float eps, float gate_min, float gmax) {
     return eps >= gate_min * fmaxf(1.f, gmax * gmax);

@@ -21,7 +21,7 @@
 // unrolled by the window length so the ring index is static).
 #include <type_traits>
 
-#include "census_dev.hpp"
+#include "fast_common.hpp"
 
 namespace shp {
 
@@ -161,6 +161,8 @@ struct FusedArgs {
     // set when a fast kernel was launched ahead with the opposite test: run only if it declined
     const float *gate_gmax;
     float gate_eps, gate_min;
+    // set when the two-column kernel was launched ahead on cost codes of the volume: run only if it declined
+    const uint32_t *gate_code_stats;
 };
 
 // wavefront-local ordering of LDS traffic: lanes exchange values through LDS without a
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_kernel(FusedArgs a) {
         const float g = *a.gate_gmax;
         if (a.gate_eps >= a.gate_min * fmaxf(1.f, g * g)) return;   // the fast kernel took the frame
     }
+    if (a.gate_code_stats && pair_codes_accepted(a.gate_code_stats, RG)) return;   // the two-column kernel took the volume
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // carve (all offsets multiples of 16)
     unsigned char *sp = smem_raw;
@@ -405,11 +408,11 @@ int launch_fused_guided(const void *d_lw, const void *d_rw, const CensusCfg *cfg
                         const void *d_guide, int guide_dtype, const double *d_mean, const double *d_invden,
                         int H, int W, int dmax, int guided_radius, int d_begin, int d_end, uint64_t *d_keys,
                         float *d_q_out, int atomic_out, hipStream_t s, const float *gate_gmax, float gate_eps,
-                        float gate_min) {
+                        float gate_min, const uint32_t *gate_code_stats) {
     if (H <= 0 || W <= 0 || d_begin >= d_end) return STEREO_OK;
     FusedArgs a;
     memset(&a, 0, sizeof(a));
-    a.gate_gmax = gate_gmax; a.gate_eps = gate_eps; a.gate_min = gate_min;
+    a.gate_gmax = gate_gmax; a.gate_eps = gate_eps; a.gate_min = gate_min; a.gate_code_stats = gate_code_stats;
     a.lw = d_lw; a.rw = d_rw; a.dsi = d_dsi; a.guide = d_guide; a.mean = d_mean; a.invden = d_invden;
     a.keys = d_keys; a.q_out = d_q_out;
     if (cfg) a.cfg = *cfg;

@@ -127,4 +127,10 @@ def test_8k_strip_matches_oracle(oracle, pair_8k, strip_volume_8k, filt):
     kind = {"gaussian": oracle.FILTER_GAUSSIAN, "bilateral": oracle.FILTER_BILATERAL}[filt]
     dref, cref, layers = _strip_reference(oracle, strip_volume_8k, kind, 0, 1.0)
     ds, cs = d[STRIP_Y0:STRIP_Y0 + STRIP_ROWS], c[STRIP_Y0:STRIP_Y0 + STRIP_ROWS]
-    assert_wta_matches(ds, cs, dref, cref, layers_ref=layers, min_agree=0.999)
+    # Gaussian: 99.9 % (measured: every disparity identical).  Bilateral: measured 99.88 - 99.89 % on this strip, with
+    # the range weights formed either on pre-scaled costs or on exact cost differences -- with sigma = 1 cost unit
+    # the filter is close to piecewise constant in its inputs, 0.1 % of the pixels have two layers within a few
+    # float32 ulps of each other, and the last bit of exp() decides between them.  The oracle cannot decide them
+    # for the reference either: with libm's expf it agrees with the reference's own NumPy result (golden fixtures
+    # wta_filters_48x80x16 / radius8_40x72x12) on 98.4 % / 99.1 % of the pixels.  Every mismatch is gap-checked.
+    assert_wta_matches(ds, cs, dref, cref, layers_ref=layers, min_agree=0.998 if filt == "bilateral" else 0.999)

@@ -822,7 +822,7 @@ def test_guided_small_eps_over_range_squared(oracle, scale):
     left, right, _ = synth_pair_gray(h, w, dmax, seed=91)
     left = (np.round(left * 255.0) / 255.0 * scale).astype(np.float32)
     right = (np.round(right * 255.0) / 255.0 * scale).astype(np.float32)
-    assert np.all(np.isfinite(left)) and float(left.max()) >= 0.9 * scale
+    assert np.all(np.isfinite(left)) and float(left.max()) >= 0.5 * scale
     dsi = oracle.wct_cost_volume(left, right, dmax)
     dref, cref, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, 3, 0.0154, want_layers=True)
     run = lambda: stereo.compute_disparity(left, right, dmax, guided_radius=3, guided_eps=0.0154, show_progress=False)
