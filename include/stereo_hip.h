@@ -89,6 +89,16 @@ int stereo_guided_prepare_host(const double *guide, int height, int width, int r
 int stereo_guided_filter_host(const double *guide, const float *src, int height, int width, int radius,
                               double eps, float *out);
 
+/* prepare_guided_filter + guided_filter_with_precompute (guided_filter.py:182-253) as the reference uses them: the
+ * guide's statistics once per scene, then one call per layer (stereo.py:143-150).  stereo_guided_plan_create uploads
+ * the guide and keeps it, its box mean and 1 / (var + eps) on the current device; stereo_guided_plan_apply moves one
+ * float32 layer in, filters it and moves the result out (same values as stereo_guided_filter_host);
+ * stereo_guided_plan_destroy releases the plan.  A plan belongs to the device it was made on and to one caller at a
+ * time. */
+int stereo_guided_plan_create(const double *guide, int height, int width, int radius, double eps, void **plan);
+int stereo_guided_plan_apply(void *plan, const float *src, float *out);
+int stereo_guided_plan_destroy(void *plan);
+
 /* ---- filters.py ------------------------------------------------------------------------ */
 /* median_filter (filters.py:227-256). mode: STEREO_FILTER_MEDIAN or STEREO_FILTER_MEDIAN_U8Q. */
 int stereo_median_filter_host(const float *image, int height, int width, int radius, int mode, float *out);

@@ -51,6 +51,9 @@ _SIGNATURES = {
     "stereo_box_filter_mean_indexed_host": [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP],
     "stereo_guided_prepare_host": [_VP, _I, _I, _I, _VP, _VP, _VP],
     "stereo_guided_filter_host": [_VP, _VP, _I, _I, _I, _D, _VP],
+    "stereo_guided_plan_create": [_VP, _I, _I, _I, _D, ctypes.POINTER(ctypes.c_void_p)],
+    "stereo_guided_plan_apply": [_VP, _VP, _VP],
+    "stereo_guided_plan_destroy": [_VP],
     "stereo_median_filter_host": [_VP, _I, _I, _I, _I, _VP],
     "stereo_median_filter_u8_host": [_VP, _I, _I, _I, _VP],
     "stereo_gaussian_filter_host": [_VP, _I, _I, _D, _VP],

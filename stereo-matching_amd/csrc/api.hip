@@ -1,5 +1,7 @@
 // C ABI of libstereo_hip.so (see include/stereo_hip.h).
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -1098,6 +1100,90 @@ int stereo_guided_filter_host(const double *guide, const float *src, int H, int 
     bool src_finite = true;
     for (size_t i = 0; i < n && src_finite; ++i) src_finite = std::fabs(src[i]) <= 3.402823466e38f;
     if (!src_finite) poison_like_reference(src, H, W, radius, fill);
+    return STEREO_OK;
+}
+
+// ---- guided filter with the guide's statistics kept on the device ---------------------------------------------
+// prepare_guided_filter / guided_filter_with_precompute (guided_filter.py:182-253): the reference computes the
+// guide's statistics once per scene and then filters layer after layer (stereo.py:143-150).  The plan is that
+// split on the device: guide, box mean and 1 / (var + eps) stay resident, a call moves one layer in and one out.
+struct GuidedPlan {
+    int H = 0, W = 0, radius = 0, device = 0;
+    double eps = 0.0;
+    bool fused = false, guide_finite = true;
+    DevBuf guide, mean, invden, gmax, src, out, keys, ws, flag;
+    std::vector<int> poison_first;   // per row: first column the reference's integral images turn into NaN (INT32_MAX: none)
+};
+
+int stereo_guided_plan_create(const double *guide, int H, int W, int radius, double eps, void **plan_out) {
+    if (!guide || !plan_out) { set_error("null pointer"); return STEREO_EINVAL; }
+    *plan_out = nullptr;
+    SHP_TRY(check_image_dims(H, W));
+    if (radius <= 0) { set_error("radius must be a positive integer"); return STEREO_EINVAL; }
+    if (!(eps > 0)) { set_error("eps must be positive"); return STEREO_EINVAL; }
+    std::unique_ptr<GuidedPlan> p(new (std::nothrow) GuidedPlan);
+    if (!p) { set_error("out of host memory"); return STEREO_ENOMEM; }
+    p->H = H; p->W = W; p->radius = radius; p->eps = eps;
+    SHP_HIP(hipGetDevice(&p->device));
+    const size_t n = (size_t)H * W;
+    SHP_TRY(p->guide.alloc(n * 8)); SHP_TRY(p->src.alloc(n * 4)); SHP_TRY(p->out.alloc(n * 4)); SHP_TRY(p->flag.alloc(4));
+    SHP_HIP(hipMemcpy(p->guide.p, guide, n * 8, hipMemcpyHostToDevice));
+    p->fused = fused_guided_supported(radius);
+    if (p->fused) {
+        SHP_TRY(p->mean.alloc(n * 8)); SHP_TRY(p->invden.alloc(n * 8)); SHP_TRY(p->keys.alloc(n * 8)); SHP_TRY(p->gmax.alloc(8));
+        SHP_TRY(launch_guide_stats(p->guide.p, STEREO_DT_F64, H, W, radius, eps, p->mean.as<double>(), p->invden.as<double>(),
+                                   p->gmax.p, nullptr));
+        SHP_TRY(guide_is_finite(p->gmax.p, &p->guide_finite));
+    } else {
+        SHP_TRY(p->ws.alloc(layered_guided_ws_bytes(H, W)));
+        SHP_TRY(layered_guided_prepare(p->guide.p, STEREO_DT_F64, H, W, radius, p->ws.p, nullptr));
+        SHP_HIP(hipDeviceSynchronize());
+        for (size_t i = 0; i < n && p->guide_finite; ++i) p->guide_finite = std::fabs(guide[i]) <= 1.7976931348623157e308;
+    }
+    if (!p->guide_finite) {
+        p->poison_first.assign(H, INT32_MAX);
+        poison_like_reference(guide, H, W, radius, [&](int y, int x0) { p->poison_first[y] = x0; });
+    }
+    *plan_out = p.release();
+    return STEREO_OK;
+}
+
+int stereo_guided_plan_apply(void *plan, const float *src, float *out) {
+    if (!plan || !src || !out) { set_error("null pointer"); return STEREO_EINVAL; }
+    GuidedPlan *p = static_cast<GuidedPlan *>(plan);
+    int dev = 0;
+    SHP_HIP(hipGetDevice(&dev));
+    if (dev != p->device) { set_error("the plan was made on device %d, the current device is %d", p->device, dev); return STEREO_EINVAL; }
+    const int H = p->H, W = p->W;
+    const size_t n = (size_t)H * W;
+    SHP_HIP(hipMemcpyAsync(p->src.p, src, n * 4, hipMemcpyHostToDevice, nullptr));
+    SHP_HIP(hipMemsetAsync(p->flag.p, 0, 4, nullptr));
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, nullptr,
+                       p->src.as<float>(), n, p->flag.as<uint32_t>());
+    SHP_LAUNCH_CHECK();
+    if (p->fused)
+        SHP_TRY(launch_fused_guided(nullptr, nullptr, nullptr, p->src.as<float>(), p->guide.p, STEREO_DT_F64, p->mean.as<double>(),
+                                    p->invden.as<double>(), H, W, 1, p->radius, 0, 1, p->keys.as<uint64_t>(), p->out.as<float>(),
+                                    0, nullptr));
+    else
+        SHP_TRY(layered_guided_apply(p->src.as<float>(), H, W, p->radius, p->eps, p->ws.p, p->out.as<float>(), nullptr));
+    SHP_HIP(hipMemcpy(out, p->out.p, n * 4, hipMemcpyDeviceToHost));
+    uint32_t src_bad = 0;
+    SHP_HIP(hipMemcpy(&src_bad, p->flag.p, 4, hipMemcpyDeviceToHost));
+    // (non-finite pixels of the guide or of the source reach, through the reference's integral images, every output
+    //  below and to the right of them: see poison_like_reference)
+    auto fill = [&](int y, int x0) {
+        for (int x = x0; x < W; ++x) out[(size_t)y * W + x] = NAN;
+    };
+    if (!p->guide_finite)
+        for (int y = 0; y < H; ++y)
+            if (p->poison_first[y] != INT32_MAX) fill(y, p->poison_first[y]);
+    if (src_bad) poison_like_reference(src, H, W, p->radius, fill);
+    return STEREO_OK;
+}
+
+int stereo_guided_plan_destroy(void *plan) {
+    delete static_cast<GuidedPlan *>(plan);   // (the device buffers go back to the library's cache)
     return STEREO_OK;
 }
 

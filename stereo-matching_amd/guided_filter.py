@@ -6,6 +6,8 @@ its private `_integral_image_numba`.  All arithmetic runs on the GPU.
 """
 from __future__ import annotations
 
+import ctypes
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -121,6 +123,38 @@ def prepare_guided_filter(guide: np.ndarray, radius: int, eps: float) -> GuidedF
                                    var_g=var_g, radius=radius, eps=float(eps))
 
 
+# Device-side plans of live GuidedFilterPrecomputed objects, keyed by id(); a plan is destroyed when its object
+# is collected (the object is a frozen dataclass, so the plan cannot live on it).
+_plans: dict = {}
+
+
+def _drop_plan(key: int) -> None:
+    handle = _plans.pop(key, None)
+    if handle is not None:
+        try:
+            _native.lib().stereo_guided_plan_destroy(handle)
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def _plan_of(precomputed: GuidedFilterPrecomputed) -> ctypes.c_void_p:
+    """The guide of `precomputed`, its box mean and 1 / (var + eps) on the device: uploaded and computed at the first
+    call for this object and kept until the object dies, so that the reference's per-layer loop (stereo.py:143-150)
+    moves one layer in and one out per call."""
+    key = id(precomputed)
+    handle = _plans.get(key)
+    if handle is None:
+        guide_f = np.ascontiguousarray(precomputed.guide_f, dtype=np.float64)
+        h, w = guide_f.shape
+        handle = ctypes.c_void_p()
+        _native.require_gpu()
+        _native.check(_native.lib().stereo_guided_plan_create(_native.ptr(guide_f), h, w, int(precomputed.radius),
+                                                              float(precomputed.eps), ctypes.byref(handle)))
+        _plans[key] = handle
+        weakref.finalize(precomputed, _drop_plan, key)
+    return handle
+
+
 def guided_filter_with_precompute(precomputed: GuidedFilterPrecomputed, src: np.ndarray) -> np.ndarray:
     """Reference guided_filter.py:220-253; returns float32 (H, W)."""
     src = np.asarray(src)
@@ -128,14 +162,12 @@ def guided_filter_with_precompute(precomputed: GuidedFilterPrecomputed, src: np.
         raise ValueError("src must be 2-D")
     if src.shape != precomputed.guide_f.shape:
         raise ValueError("src and guide sizes differ")
-    src_f = np.ascontiguousarray(src.astype(np.float32))
-    guide_f = np.ascontiguousarray(precomputed.guide_f, dtype=np.float64)
+    src_f = np.ascontiguousarray(src, dtype=np.float32)
     h, w = src_f.shape
     out = np.empty((h, w), dtype=np.float32)
-    _native.require_gpu()
-    _native.check(_native.lib().stereo_guided_filter_host(
-        _native.ptr(guide_f), _native.ptr(src_f), h, w, int(precomputed.radius), float(precomputed.eps),
-        _native.ptr(out)))
+    if h == 0 or w == 0:
+        return out
+    _native.check(_native.lib().stereo_guided_plan_apply(_plan_of(precomputed), _native.ptr(src_f), _native.ptr(out)))
     return out
 
 

@@ -241,3 +241,80 @@ def test_cli_single_scene_in_a_process_group(oracle, tmp_path):
     metrics = json.loads((result / runs[0] / "metrics.json").read_text())
     pbm, rms, n = oracle.pbm_rms(disp, gt, mask, 2.0)
     assert metrics["pbm"] == pbm and "PBM:" in out.stdout
+
+
+# Full-resolution shapes (width, height, ndisp) of the 23 scenes the reference's batch mode runs (the list of
+# ensure_dataset.py:16-40; Motorcycle from its calib.txt, the others approximate): heterogeneous, ndisp from 180 to
+# 1110.  The rehearsal below uses them at a quarter of the size in every dimension.
+MIDDLEBURY_2014_SHAPES = {
+    "Adirondack": (2880, 1988, 290), "Backpack": (2948, 1988, 260), "Bicycle1": (2988, 2008, 180),
+    "Cable": (2796, 1992, 460), "Classroom1": (3000, 1920, 260), "Couch": (2296, 1992, 630),
+    "Flowers": (2880, 1980, 640), "Jadeplant": (2632, 1988, 640), "Mask": (2792, 2008, 460),
+    "Motorcycle": (2964, 2000, 270), "Piano": (2820, 1920, 260), "Pipes": (2960, 1924, 300),
+    "Playroom": (2800, 1908, 330), "Playtable": (2724, 1848, 290), "Recycle": (2880, 1924, 260),
+    "Shelves": (2952, 1988, 240), "Shopvac": (2356, 1996, 1110), "Sticks": (2864, 2000, 300),
+    "Storage": (2792, 1988, 660), "Sword1": (2912, 2020, 260), "Sword2": (2856, 2000, 370),
+    "Umbrella": (2960, 2016, 250), "Vintage": (2912, 1924, 760),
+}
+
+
+def test_all_datasets_rehearsal_23_scenes(oracle, tmp_path, capsys):
+    """`stereo.py --all-datasets --bad_threshold 1.0 --guided_eps 0.0154` (reference stereo.py:722-778) on 23
+    synthetic scenes in the dataset's layout, named and shaped like the Middlebury 2014 "perfect" scenes at a quarter
+    of their size: every scene's disparity map against the oracle pipeline (>= 99.9 % identical), its bad-1.0
+    percentage against the one computed from the oracle's map, metrics_summary.json in the reference's schema, and
+    the spread of the scene dealer's load over 8 ranks.  The dataset itself is not available offline: parity on the
+    real scenes stays unpinned."""
+    import sharding
+    import stereo
+    import stereo_io
+
+    root = tmp_path / "dataset"
+    shapes = {}
+    lines = ["scene,ndisp"]
+    for i, (name, (fw, fh, fd)) in enumerate(sorted(MIDDLEBURY_2014_SHAPES.items())):
+        w, h, nd = fw // 4, fh // 4, fd // 4
+        shapes[f"{name}-perfect"] = (h, w, nd)
+        _write_scene(str(root / f"{name}-perfect"), h, w, nd, 100 + i)
+        lines.append(f"{name}-perfect,{nd}")
+    (root / "ndisp_summary.csv").write_text("\n".join(lines) + "\n", encoding="utf-8")
+    result = tmp_path / "result"
+    stereo.main(["--all-datasets", "--bad_threshold", "1.0", "--guided_eps", "0.0154"], dataset_root=str(root),
+                result_root=str(result))
+    capsys.readouterr()
+    (run,) = sorted(os.listdir(result))
+    batch = result / run
+    summary = json.loads((batch / "metrics_summary.json").read_text())
+    assert sorted(summary) == ["bad_threshold", "pbm_mean", "rms_mean", "scene_count", "scenes"]
+    assert summary["scene_count"] == 23 and summary["bad_threshold"] == 1.0
+    assert list(summary["scenes"]) == sorted(shapes)
+    assert summary["pbm_mean"] == float(np.mean([m["pbm"] for m in summary["scenes"].values()]))
+    assert summary["rms_mean"] == float(np.mean([m["rms"] for m in summary["scenes"].values()]))
+    worst_agree, worst_pbm = 1.0, 0.0
+    for name, (h, w, nd) in shapes.items():
+        folder = str(root / name)
+        lg = oracle.to_gray(stereo_io.read_image(os.path.join(folder, "im0.png")), normalize=True)
+        rg = oracle.to_gray(stereo_io.read_image(os.path.join(folder, "im1.png")), normalize=True)
+        want_d, _ = oracle.compute_disparity_allcores(lg, rg, nd, wct_radius=4, radius=3, eps=0.0154)
+        gt = stereo_io.read_pfm(os.path.join(folder, "disp0.pfm"))
+        mask = stereo_io.read_pgm_mask(os.path.join(folder, "disp0-n.pgm"))
+        d, _ = stereo_io.load_disparity_npz(str(batch / name / "disparity.npz"))
+        got = summary["scenes"][name]
+        assert set(got) == {"pbm", "rms", "bad_threshold", "valid_pixel_count"} and got["bad_threshold"] == 1.0
+        # the file's figures are those of the map that was written ...
+        pbm, rms, n = oracle.pbm_rms(d, gt, mask, 1.0)
+        assert got["pbm"] == pbm and abs(got["rms"] - rms) <= 1e-6 * max(rms, 1e-30) and got["valid_pixel_count"] == float(n)
+        # ... and the map is the oracle's but for near-ties, so bad-1.0 agrees to within the pixels that differ
+        agree = float(np.mean(d == want_d))
+        pbm_ref, _, n_ref = oracle.pbm_rms(want_d, gt, mask, 1.0)
+        assert agree >= 0.999 and n_ref == n
+        assert abs(pbm - pbm_ref) <= 100.0 * float(np.sum(d != want_d)) / n
+        worst_agree, worst_pbm = min(worst_agree, agree), max(worst_pbm, abs(pbm - pbm_ref))
+    print(f"23 scenes: lowest disparity agreement {worst_agree:.6f}, largest bad-1.0 difference {worst_pbm:.5f} points")
+    # the dealer: longest scene first onto the least loaded rank (8 ranks: one GPU node)
+    sizes = [h * w * nd for (h, w, nd) in (shapes[s] for s in sorted(shapes))]
+    plan = sharding.deal_scenes(sizes, 8)
+    assert sorted(i for p in plan for i in p) == list(range(23))
+    loads = [sum(sizes[i] for i in p) for p in plan]
+    assert max(loads) <= 4.0 / 3.0 * max(sum(sizes) / 8.0, max(sizes))
+    print(f"dealer: loads max / mean = {max(loads) / (sum(sizes) / 8.0):.3f}")

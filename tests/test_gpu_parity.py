@@ -830,3 +830,46 @@ def test_guided_small_eps_over_range_squared(oracle, scale):
     assert_wta_matches(d, c, dref, cref, layers, min_agree=0.99)
     d_gen, c_gen = _with_kernel(1, run)
     assert rel_err(c, c_gen) <= 2e-6
+
+
+def test_guided_precompute_keeps_the_statistics_on_the_device(oracle):
+    """prepare_guided_filter + guided_filter_with_precompute layer after layer (reference guided_filter.py:182-253,
+    the loop of stereo.py:143-150): the guide and its statistics are uploaded once per GuidedFilterPrecomputed object;
+    every layer equals guided_filter's result bit for bit and the oracle's within 1e-5; NaN / inf pixels of the guide
+    or of a layer spread as in the reference; the device plan dies with the object."""
+    import gc
+
+    import guided_filter as gf
+    from synth import synth_pair_gray
+    h, w, dmax = 70, 150, 9
+    left, right, _ = synth_pair_gray(h, w, dmax, seed=12)
+    dsi = oracle.wct_cost_volume(left, right, dmax)
+    for radius in (3, 9):            # fused kernel / layer-at-a-time chain
+        before = len(gf._plans)
+        pre = gf.prepare_guided_filter(left, radius, 0.0154)
+        for d in range(dmax):
+            layer = dsi[:, :, d]     # a strided view, as the reference passes it
+            got = gf.guided_filter_with_precompute(pre, layer)
+            assert got.dtype == np.float32 and np.array_equal(got, gf.guided_filter(left, layer, radius, 0.0154))
+            assert rel_err(got, oracle.guided_filter(left, layer, radius, 0.0154)) <= TOL
+        assert len(gf._plans) == before + 1      # one plan, made at the first call
+        bad_layer = dsi[:, :, 3].copy()
+        bad_layer[40, 100] = np.inf
+        got = gf.guided_filter_with_precompute(pre, bad_layer)
+        want = gf.guided_filter(left, bad_layer, radius, 0.0154)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).any()
+        assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+        del pre
+        gc.collect()
+        assert len(gf._plans) == before
+        bad_guide = left.copy()
+        bad_guide[30, 90] = np.nan
+        pre = gf.prepare_guided_filter(bad_guide, radius, 0.0154)
+        got = gf.guided_filter_with_precompute(pre, dsi[:, :, 2])
+        want = gf.guided_filter(bad_guide, dsi[:, :, 2], radius, 0.0154)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).any()
+        assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+        del pre
+        gc.collect()
+    with pytest.raises(ValueError):
+        gf.guided_filter_with_precompute(gf.prepare_guided_filter(left, 3, 0.0154), dsi[:10, :, 0])
