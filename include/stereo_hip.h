@@ -229,6 +229,13 @@ int stereo_compute_disparity_progress_dev(const float *d_left, const float *d_ri
                                           size_t workspace_bytes, uint64_t *d_keys, int n_bands,
                                           uint32_t *d_progress, uint32_t epoch, void *stream);
 int stereo_wait_progress_dev(const uint32_t *d_progress, int band, uint32_t epoch, void *stream);
+/* Whether work on stream_b can run while a kernel enqueued earlier on stream_a is still running.  The HIP runtime
+ * maps streams onto a few hardware queues, and two streams on the same queue run in submission order: a band wait
+ * enqueued on such a stream would only start after the search.  A caller that sets up a side stream for
+ * stereo_wait_progress_dev tries candidates with this call (it runs two tiny kernels, synchronises both streams and
+ * allocates a few words: set-up time only) and keeps one that reports *overlap = 1.  Do not give the side stream a
+ * higher priority instead: a polling wait on a high-priority queue was seen to hold back the search it waits for. */
+int stereo_streams_overlap(void *stream_a, void *stream_b, int *overlap);
 
 /* The host entry points keep the device buffers they allocate in a per-process cache (at most 8 GiB
  * idle) so that a caller processing frame after frame does not pay hipMalloc / hipFree per call;

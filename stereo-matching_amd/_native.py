@@ -73,6 +73,7 @@ _SIGNATURES = {
     "stereo_compute_disparity_progress_dev": [_VP, _VP, _I, _I, _I, _PP, _I, _I, _VP, _SZ, _VP, _I, _VP, ctypes.c_uint32,
                                               _VP],
     "stereo_wait_progress_dev": [_VP, _I, ctypes.c_uint32, _VP],
+    "stereo_streams_overlap": [_VP, _VP, ctypes.POINTER(ctypes.c_int)],
     "stereo_merge_keys_dev": [_VP, _VP, _SZ, _VP],
     "stereo_merge_key_slices_dev": [_VP, _SZ, _I, _VP],
     "stereo_keys_to_i64_dev": [_VP, _VP, _SZ, _VP],

@@ -189,15 +189,21 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
     void *lw = base + L.off_lw, *rw = base + L.off_rw;
     double *mean = reinterpret_cast<double *>(base + L.off_mean);
     double *invden = reinterpret_cast<double *>(base + L.off_invden);
-    SHP_TRY(launch_census_pack_pair(d_left, d_right, STEREO_DT_F32, H, W, p->wct_radius, lw, rw, s));
+    const bool merged_prepass = p->filter_kind == STEREO_FILTER_GUIDED && census_stats_merged(p->wct_radius, p->guided_radius);
+    if (!merged_prepass) SHP_TRY(launch_census_pack_pair(d_left, d_right, STEREO_DT_F32, H, W, p->wct_radius, lw, rw, s));
     if (p->filter_kind == STEREO_FILTER_GUIDED) {
         if (!fused_guided_supported(p->guided_radius)) {
             set_error("fused guided path supports radius 1..8, got %d", p->guided_radius);
             return STEREO_EUNSUPPORTED;
         }
         float *gmax = reinterpret_cast<float *>(base + L.off_gmax);
-        SHP_TRY(launch_guide_stats(d_left, STEREO_DT_F32, H, W, p->guided_radius, p->guided_eps, mean, invden,
-                                   gmax, s));
+        // (census words of both images and the guide statistics: one launch where the radii allow it)
+        if (merged_prepass)
+            SHP_TRY(launch_census_stats(d_left, d_right, H, W, p->wct_radius, p->guided_radius, p->guided_eps, lw, rw, mean,
+                                        invden, gmax, s));
+        else
+            SHP_TRY(launch_guide_stats(d_left, STEREO_DT_F32, H, W, p->guided_radius, p->guided_eps, mean, invden,
+                                       gmax, s));
         if (d_begin == d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
         // The fast kernels evaluate the second box stage in float32: its terms grow like 1 / sqrt(eps), and
         // below this eps their rounding can exceed 1e-5 of a cost unit where the filtered cost is near zero.
@@ -771,6 +777,14 @@ int stereo_compute_disparity_progress_dev(const float *d_left, const float *d_ri
     return rc != STEREO_OK ? rc : rc2;
 }
 
+int stereo_streams_overlap(void *stream_a, void *stream_b, int *overlap) {
+    if (!overlap) { set_error("null pointer"); return STEREO_EINVAL; }
+    bool o = false;
+    SHP_TRY(streams_overlap(static_cast<hipStream_t>(stream_a), static_cast<hipStream_t>(stream_b), &o));
+    *overlap = o ? 1 : 0;
+    return STEREO_OK;
+}
+
 int stereo_wait_progress_dev(const uint32_t *d_progress, int band, uint32_t epoch, void *stream) {
     if (!d_progress) { set_error("null pointer"); return STEREO_EINVAL; }
     return launch_progress_wait(d_progress, band, epoch, static_cast<hipStream_t>(stream));
@@ -855,7 +869,23 @@ static HostOverlap *host_overlap_for_current_device() {
         hipStream_t a = nullptr, b = nullptr;
         hipEvent_t e = nullptr;
         if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipStreamCreateWithFlags(&b, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(a); return nullptr; }
+        // The copy stream must not share a hardware queue with the compute stream (its band waits would start
+        // after the search): of up to eight new streams the first one whose work runs beside the compute stream's
+        // is kept (streams_overlap); if none does, the last one serves -- correct, merely without the overlap.
+        // (rejected candidates stay alive until the choice is made: a destroyed stream's queue slot could be handed
+        //  to the next candidate)
+        std::vector<hipStream_t> rejected;
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            hipStream_t c = nullptr;
+            if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+            bool overlap = false;
+            const bool probed = streams_overlap(a, c, &overlap) == STEREO_OK;
+            if (b) rejected.push_back(b);
+            b = c;
+            if (!probed || overlap) break;
+        }
+        for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+        if (!b) { (void)hipStreamDestroy(a); return nullptr; }
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
             (void)hipStreamDestroy(a); (void)hipStreamDestroy(b);
             return nullptr;

@@ -10,7 +10,7 @@
 // 2^(field_bits - r), so the field of L^R read as an integer IS that direction's weighted
 // Hamming cost in units of base/2^(field_bits-1).  The whole cost is then the sum of the
 // fields: one v_dot8_u32_u4 (or two v_dot4_u32_u8) per evaluation.
-#include "census_dev.hpp"
+#include "fast_common.hpp"
 
 namespace shp {
 
@@ -156,6 +156,144 @@ __global__ __launch_bounds__(256) void census_pack_kernel(const T *__restrict__ 
         if (FB > R) word <<= (FB - R);
         if (gy < H && gx < W) words[(size_t)gy * W + gx] = word;
     }
+}
+
+// The pre-pass of the fused guided path in one launch: census words of both images and, from the left image's tile
+// while it is in LDS, the guide statistics of the guided filter (guided_filter.py:202-216: box mean of the guide and
+// 1 / (var + eps32), float64, clipped windows; the largest finite |guide| and a non-finite flag for the kernels'
+// scaling).  float32 images; the guided radius may not exceed the census radius (the tile's halo).  Window means
+// multiply by the reciprocal of the window area (a compile-time constant for full windows) instead of dividing: one
+// float64 division per pixel instead of three, at most one unit in the last place of the mean.
+template <typename WordT, int R, int RG>
+__global__ __launch_bounds__(256) void census_stats_kernel(const float *__restrict__ img0, const float *__restrict__ img1,
+                                                           int H, int W, WordT *__restrict__ words0,
+                                                           WordT *__restrict__ words1, double eps32,
+                                                           double *__restrict__ mean, double *__restrict__ invden,
+                                                           unsigned int *gmax_bits) {
+    static_assert(RG >= 1 && RG <= R, "the statistics' windows must fit the census tile's halo");
+    constexpr int LW = CP_TW + 2 * R, LH = CP_TH + 2 * R;
+    constexpr int FB = (sizeof(WordT) == 8) ? 8 : 4;
+    constexpr int SH = CP_TH + 2 * RG;           // rows of horizontal window sums
+    __shared__ float tile[LH * LW];               // census: cells outside the image hold the lowest value
+    __shared__ float gtile[LH * LW];              // statistics: cells outside the image hold 0 (clipped windows)
+    __shared__ double hs1[SH * CP_TW], hs2[SH * CP_TW];
+    const bool left = blockIdx.z == 0;
+    const float *__restrict__ img = left ? img0 : img1;
+    WordT *__restrict__ words = left ? words0 : words1;
+    const int x0 = blockIdx.x * CP_TW, y0 = blockIdx.y * CP_TH;
+    constexpr int NLD = (LW * LH + 255) / 256;
+    float v[NLD];
+    bool in[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int i = min((int)threadIdx.x + u * 256, LW * LH - 1);
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = y0 - R + ly, gx = x0 - R + lx;
+        in[u] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        v[u] = img[(size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+        if ((int)threadIdx.x + u * 256 < LW * LH) {
+            tile[threadIdx.x + u * 256] = in[u] ? v[u] : census_lowest<float>();
+            if (left) gtile[threadIdx.x + u * 256] = in[u] ? v[u] : 0.f;
+        }
+    __syncthreads();
+    constexpr int dys[8] = {1, -1, 0, 0, 1, 1, -1, -1};
+    constexpr int dxs[8] = {0, 0, 1, -1, 1, -1, 1, -1};
+    const int lx = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < CP_TH / 4; ++i) {
+        const int ly = (threadIdx.x >> 6) + 4 * i;
+        const int gy = y0 + ly, gx = x0 + lx;
+        const float *c0 = tile + (ly + R) * LW + (lx + R);
+        const float c = *c0;
+        WordT word = 0;
+#pragma unroll
+        for (int k = 7; k >= 0; --k) {
+#pragma unroll
+            for (int r = 1; r <= R; ++r) word = shift_in_greater(word, c0[dys[k] * r * LW + dxs[k] * r], c);
+            if (FB > R) word <<= (k > 0 ? FB - R : 0);
+        }
+        if (FB > R) word <<= (FB - R);
+        if (gy < H && gx < W) words[(size_t)gy * W + gx] = word;
+    }
+    if (!left) return;
+    // horizontal window sums of G and G * G for the rows the tile's vertical windows reach
+    for (int i = threadIdx.x; i < SH * CP_TW; i += 256) {
+        const int r = i >> 6, cx = i & 63;
+        const float *row = gtile + (r + R - RG) * LW + (cx + R - RG);
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k <= 2 * RG; ++k) {
+            const double g = (double)row[k];
+            s1 += g;
+            s2 = fma(g, g, s2);
+        }
+        hs1[i] = s1;
+        hs2[i] = s2;
+    }
+    __syncthreads();
+    float amax = 0.f;   // largest finite |guide| of the tile
+    bool nonfinite = false;
+    constexpr double RA_FULL = 1.0 / (double)((2 * RG + 1) * (2 * RG + 1));
+#pragma unroll
+    for (int i = 0; i < CP_TH / 4; ++i) {
+        const int ly = (threadIdx.x >> 6) + 4 * i;
+        const int gy = y0 + ly, gx = x0 + lx;
+        if (gy >= H || gx >= W) continue;
+        const float gv = gtile[(ly + R) * LW + lx + R];
+        if (fabsf(gv) <= 3.402823466e38f) amax = fmaxf(amax, fabsf(gv));
+        else nonfinite = true;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k <= 2 * RG; ++k) {
+            s1 += hs1[(ly + k) * CP_TW + lx];
+            s2 += hs2[(ly + k) * CP_TW + lx];
+        }
+        const int cy = min(gy + RG, H - 1) - max(gy - RG, 0) + 1;
+        const int cx = min(gx + RG, W - 1) - max(gx - RG, 0) + 1;
+        double m, inv;
+        guide_mean_invden(s1, s2, cy, cx, (2 * RG + 1) * (2 * RG + 1), RA_FULL, eps32, &m, &inv);
+        mean[(size_t)gy * W + gx] = m;
+        invden[(size_t)gy * W + gx] = inv;
+    }
+    unsigned int b = __float_as_uint(amax);
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned int o = __shfl_down(b, off, 64);
+        b = o > b ? o : b;
+    }
+    // read first: almost every wavefront sees a value already at least as large
+    if ((threadIdx.x & 63) == 0 && b > *static_cast<volatile unsigned int *>(gmax_bits)) atomicMax(gmax_bits, b);
+    if (nonfinite) gmax_bits[1] = 1u;   // second word: some guide pixel is NaN or infinite
+}
+
+bool census_stats_merged(int census_radius, int guided_radius) {
+    return (census_radius == 4 || census_radius == 8) && guided_radius >= 1 && guided_radius <= 4;
+}
+
+// census words of both float32 images + the left image's guide statistics, one launch (see census_stats_kernel);
+// d_gmax: 8 bytes, cleared here
+int launch_census_stats(const float *d_left, const float *d_right, int H, int W, int census_radius, int guided_radius,
+                        double eps, void *d_lw, void *d_rw, double *d_mean, double *d_invden, void *d_gmax, hipStream_t s) {
+    if (H <= 0 || W <= 0) return STEREO_OK;
+    if (!census_stats_merged(census_radius, guided_radius)) {
+        set_error("no merged pre-pass for census radius %d, guided radius %d", census_radius, guided_radius);
+        return STEREO_EUNSUPPORTED;
+    }
+    unsigned int *gmax_bits = static_cast<unsigned int *>(d_gmax);
+    SHP_HIP(hipMemsetAsync(gmax_bits, 0, 8, s));
+    const double eps32 = (double)(float)eps;   // guided_filter.py:245 rounds eps to float32
+    dim3 grid(ceil_div(W, CP_TW), ceil_div(H, CP_TH), 2);
+#define SHP_CS_CASE(WT, RR, GG)                                                                                          \
+    if (census_radius == RR && guided_radius == GG)                                                                      \
+        hipLaunchKernelGGL((census_stats_kernel<WT, RR, GG>), grid, dim3(256), 0, s, d_left, d_right, H, W,               \
+                           static_cast<WT *>(d_lw), static_cast<WT *>(d_rw), eps32, d_mean, d_invden, gmax_bits);
+    SHP_CS_CASE(uint32_t, 4, 1) SHP_CS_CASE(uint32_t, 4, 2) SHP_CS_CASE(uint32_t, 4, 3) SHP_CS_CASE(uint32_t, 4, 4)
+    SHP_CS_CASE(uint64_t, 8, 1) SHP_CS_CASE(uint64_t, 8, 2) SHP_CS_CASE(uint64_t, 8, 3) SHP_CS_CASE(uint64_t, 8, 4)
+#undef SHP_CS_CASE
+    SHP_LAUNCH_CHECK();
+    return STEREO_OK;
 }
 
 template <typename T, typename WordT>

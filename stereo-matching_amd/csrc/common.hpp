@@ -111,6 +111,10 @@ int make_census_cfg(int radius, double base_weight, CensusCfg *cfg);
 int launch_census_pack(const void *d_img, int dtype, int H, int W, int radius, void *d_words, hipStream_t s);
 int launch_census_pack_pair(const void *d_img0, const void *d_img1, int dtype, int H, int W, int radius, void *d_words0,
                             void *d_words1, hipStream_t s);
+// the pre-pass of the fused guided path as one launch (census.hip): applies to float32 images with these radii
+bool census_stats_merged(int census_radius, int guided_radius);
+int launch_census_stats(const float *d_left, const float *d_right, int H, int W, int census_radius, int guided_radius,
+                        double eps, void *d_lw, void *d_rw, double *d_mean, double *d_invden, void *d_gmax, hipStream_t s);
 int launch_dsi(const void *d_lw, const void *d_rw, int H, int W, int dmax, const CensusCfg &cfg, float *d_dsi,
                hipStream_t s);
 int launch_unpack_keys(const uint64_t *keys, size_t n, int32_t *disp, float *cost, hipStream_t s);
@@ -161,6 +165,7 @@ int launch_encode_cost_codes(const float *d_dsi, int H, int W, int D, int d_begi
                              uint32_t *d_stats, hipStream_t s);
 int launch_progress_finish(uint32_t *words, int n_bands, uint32_t epoch, hipStream_t s);
 int launch_progress_wait(const uint32_t *words, int band, uint32_t epoch, hipStream_t s);
+int streams_overlap(hipStream_t a, hipStream_t b, bool *overlap);   // set-up time only: synchronises and allocates
 bool fused_fast_supported(const CensusCfg &cfg, int guided_radius);
 int fused_fast_slices(int H, int W, int guided_radius, int n_disp);
 int launch_fused_guided_fast(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,

@@ -82,6 +82,23 @@ __device__ __forceinline__ bool eps_gate_takes_fast(float eps, float gate_min, f
     return eps >= gate_min * fmaxf(1.f, gmax * gmax);
 }
 
+// Box mean of the guide and 1 / (var + eps32) from a clipped window's sums of G and G * G over cy x cx pixels
+// (guided_filter.py:202-216, :245-248).  The means multiply by the reciprocal of the window area -- for a full
+// window of `full_area` pixels a value formed once -- instead of dividing: one float64 division per pixel instead of
+// three.  Every kernel that forms guide statistics goes through here, so that they agree to the last bit.
+__device__ __forceinline__ void guide_mean_invden(double s1, double s2, int cy, int cx, int full_area, double rcp_full_area,
+                                                  double eps32, double *mean, double *invden) {
+    double ra = rcp_full_area;
+    if (cy * cx != full_area) ra = 1.0 / (double)(cy * cx);
+    const double m = s1 * ra;
+    double var = fma(-m, m, s2 * ra);
+    var = var > 0.0 ? var : (var != var ? var : 0.0);
+    double den = var + eps32;
+    if (den <= 0.0) den = eps32;
+    *mean = m;
+    *invden = 1.0 / den;
+}
+
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
 

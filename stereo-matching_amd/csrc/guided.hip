@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__
         _Pragma("unroll") for (int k = 0; k <= 2 * R; ++k) {
             double g = tile[ly * LW + lx + k];
             s1 += g;
-            s2 += g * g;
+            s2 = fma(g, g, s2);
         }
         hs1[i] = s1;
         hs2[i] = s2;
@@ -88,15 +88,11 @@ __global__ __launch_bounds__(256) void guide_stats_kernel(const GT *__restrict__
         }
         int cy = min(gy + R, H - 1) - max(gy - R, 0) + 1;
         int cx = min(gx + R, W - 1) - max(gx - R, 0) + 1;
-        double area = (double)(cy * cx);
-        double m = s1 / area;
-        double mgg = s2 / area;
-        double var = mgg - m * m;
-        var = var > 0.0 ? var : (var != var ? var : 0.0);
-        double den = var + eps32;
-        if (den <= 0.0) den = eps32;
+        const int full_area = (2 * R + 1) * (2 * R + 1);
+        double m, inv;
+        guide_mean_invden(s1, s2, cy, cx, full_area, 1.0 / (double)full_area, eps32, &m, &inv);
         mean[(size_t)gy * W + gx] = m;
-        invden[(size_t)gy * W + gx] = 1.0 / den;
+        invden[(size_t)gy * W + gx] = inv;
     }
     if (gmax_bits) {
         unsigned int b = __float_as_uint(amax);

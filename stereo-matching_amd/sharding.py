@@ -134,7 +134,7 @@ class OverlappedExchange:
         self.use_dist = (world > 1) if use_dist is None else use_dist
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
-        self.side = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.side = self._side_stream() if self.on_gpu else None
         self.epoch = 0
         n = height * width
         last_first = (row_end[-2] if len(row_end) > 1 else 0) * width
@@ -157,6 +157,36 @@ class OverlappedExchange:
                        if self.use_dist and rank == 0 else None)
             self.bands.append(b)
             y0 = y1
+
+    def _side_stream(self):
+        """A stream whose work runs BESIDE the current stream's.  The runtime maps streams onto a few hardware queues
+        (four by default) and serves two streams that share one in submission order: waits and collectives on such a
+        side stream would queue up behind the search instead of accompanying it (seen on this stack: the first side
+        stream PyTorch hands out and the default stream share a queue).  The mapping cannot be asked for, so
+        candidates are tried with stereo_streams_overlap and the first that overlaps is kept; if none does, the last
+        one serves -- correct, merely without the overlap.  (Not a high-priority stream: a polling wait on a
+        high-priority queue was seen to hold back the search it waits for, for as long as the wait's time limit.)"""
+        import ctypes
+
+        import torch
+
+        import _native
+
+        lib = _native.lib()
+        main = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self.side_overlaps = False
+        self._candidates = []   # kept alive: a stream that is released may be handed out again as the next candidate
+        side = None
+        with torch.cuda.device(self.device):
+            for _ in range(8):
+                side = torch.cuda.Stream(device=self.device)
+                self._candidates.append(side)
+                overlap = ctypes.c_int(0)
+                _native.check(lib.stereo_streams_overlap(main, ctypes.c_void_p(side.cuda_stream), ctypes.byref(overlap)))
+                if overlap.value:
+                    self.side_overlaps = True
+                    break
+        return side
 
     def run(self, search_fn: Callable, wait_band_fn: Callable, merge_fn: Callable, unpack_fn: Callable) -> None:
         import contextlib
