@@ -215,7 +215,7 @@ static int fused_disparity_dev(const float *d_left, const float *d_right, int H,
         const bool pair_precise = pair_cfg && p->guided_radius <= 4 && (g_force_kernel == 3 || p->guided_eps >= PRECISE_KERNEL_MIN_EPS);
         const bool fast = !pair_cfg && fused_fast_supported(cfg, p->guided_radius) && g_force_kernel != 1 && eps_ok;
         const int slices = (pair || pair_precise) ? fused_pair_slices(H, W, p->guided_radius, cfg.word64 != 0, d_end - d_begin)
-                           : fast ? fused_fast_slices(H, W, p->guided_radius, d_end - d_begin) : 1;
+                           : fast ? fused_fast_slices(H, W, p->guided_radius, d_end - d_begin, cfg.word64 != 0) : 1;
         if (slices > 1) SHP_TRY(launch_fill_keys(d_keys, (size_t)H * W, s));
         const bool prof = g_prof.enabled && g_prof.used < (int)g_prof.start.size();
         if (prof) SHP_HIP(hipEventRecord(g_prof.start[g_prof.used], s));

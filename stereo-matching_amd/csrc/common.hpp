@@ -167,7 +167,7 @@ int launch_progress_finish(uint32_t *words, int n_bands, uint32_t epoch, hipStre
 int launch_progress_wait(const uint32_t *words, int band, uint32_t epoch, hipStream_t s);
 int streams_overlap(hipStream_t a, hipStream_t b, bool *overlap);   // set-up time only: synchronises and allocates
 bool fused_fast_supported(const CensusCfg &cfg, int guided_radius);
-int fused_fast_slices(int H, int W, int guided_radius, int n_disp);
+int fused_fast_slices(int H, int W, int guided_radius, int n_disp, bool word64 = false);
 int launch_fused_guided_fast(const void *d_lw, const void *d_rw, const CensusCfg &cfg, const float *d_guide,
                              const double *d_mean, const double *d_invden, const float *d_gmax, int H, int W,
                              int dmax, int guided_radius, int d_begin, int d_end, int n_slices, uint64_t *d_keys,

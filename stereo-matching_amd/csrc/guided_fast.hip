@@ -1,5 +1,5 @@
 // Fast path of the fused census-cost + guided-filter + WTA kernel (float32 guide, exactly
-// summable census weights, guided radius <= 4).  Same decomposition as guided.hip -- a
+// summable census weights, guided radius 1..4 and 6..8; the two-column kernel serves 1..5 by default).  Same decomposition as guided.hip -- a
 // workgroup owns a TH x (64 - 4r) tile, each wavefront marches down the tile rows for one
 // disparity at a time with one lane per column -- but the horizontal box sums never touch LDS:
 //
@@ -34,7 +34,7 @@ struct TileLds {
     uint64_t *key;   // [TH][64] packed (cost, d); every lane owns a slot, only the inner ones are written out
     double *iay1;    // [NJ] 1 / (rows of the clipped window), 0 outside the image
     float *cy2;      // [TH] rows of the clipped window of the output rows (0 outside the image)
-    double *invtab;  // [16] 1/n
+    double *invtab;  // [32] 1/n
     WordT *L;        // [NI][64] left census words
     float *inv;      // [NJ][64] 1 / ((var + eps) * window area)
     float *glo;      // [NI][64] guide - k * 2^-s
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void fused_guided_fast_kernel(FastArgs a) 
     t.key = reinterpret_cast<uint64_t *>(sp); sp += sizeof(uint64_t) * TH * 64;
     t.iay1 = reinterpret_cast<double *>(sp); sp += sizeof(double) * ((NJ + 1) / 2 * 2);
     t.cy2 = reinterpret_cast<float *>(sp); sp += sizeof(double) * ((TH + 1) / 2 * 2);
-    t.invtab = reinterpret_cast<double *>(sp); sp += sizeof(double) * 16;
+    t.invtab = reinterpret_cast<double *>(sp); sp += sizeof(double) * 32;
     t.L = reinterpret_cast<WordT *>(sp); sp += sizeof(WordT) * NI * 64;
     t.inv = reinterpret_cast<float *>(sp); sp += sizeof(float) * NJ * 64;
     t.glo = reinterpret_cast<float *>(sp); sp += sizeof(float) * NI * 64;
@@ -383,6 +383,14 @@ template <> struct FastTile<1, true> { static constexpr int TH = 62; };
 template <> struct FastTile<2, true> { static constexpr int TH = 62; };
 template <> struct FastTile<3, true> { static constexpr int TH = 58; };
 template <> struct FastTile<4, true> { static constexpr int TH = 56; };
+// radii 6 .. 8: 13- to 17-row windows, 40 / 36 / 32 output columns per wavefront; the rings of the vertical windows
+// need the registers of two wavefronts per SIMD (workgroups of 8 wavefronts)
+template <> struct FastTile<6, false> { static constexpr int TH = 54; };
+template <> struct FastTile<7, false> { static constexpr int TH = 47; };
+template <> struct FastTile<8, false> { static constexpr int TH = 53; };
+template <> struct FastTile<6, true> { static constexpr int TH = 41; };
+template <> struct FastTile<7, true> { static constexpr int TH = 47; };
+template <> struct FastTile<8, true> { static constexpr int TH = 36; };
 #ifndef FF_NW
 #define FF_NW 16
 #endif
@@ -393,7 +401,7 @@ static int launch_fast_q(const FastArgs &a, hipStream_t s) {
     constexpr int NI = TH + 4 * RG, NJ = TH + 2 * RG, TWV = 64 - 4 * RG;
     using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
     constexpr size_t smem = sizeof(double) * NJ * 64 + sizeof(uint64_t) * TH * 64 + sizeof(double) * ((NJ + 1) / 2 * 2) +
-                            sizeof(double) * ((TH + 1) / 2 * 2) + sizeof(double) * 16 + sizeof(WordT) * NI * 64 +
+                            sizeof(double) * ((TH + 1) / 2 * 2) + sizeof(double) * 32 + sizeof(WordT) * NI * 64 +
                             sizeof(float) * NJ * 64 + sizeof(float) * NI * 64 + sizeof(float) * (TH * 64 + 16) + 16 +
                             sizeof(short) * NI * 64;
     static_assert(smem <= 160 * 1024, "tile image exceeds the LDS");
@@ -407,20 +415,35 @@ static int launch_fast_q(const FastArgs &a, hipStream_t s) {
 }
 template <int RG, bool WORD64>
 static int launch_fast_t(const FastArgs &a, hipStream_t s) {
-    return a.q_out ? launch_fast_q<RG, WORD64, true>(a, s) : launch_fast_q<RG, WORD64, false>(a, s);
+    constexpr int NWV = RG >= 5 ? 8 : FF_NW;
+    return a.q_out ? launch_fast_q<RG, WORD64, true, NWV>(a, s) : launch_fast_q<RG, WORD64, false, NWV>(a, s);
 }
 
 bool fused_fast_supported(const CensusCfg &cfg, int guided_radius) {
-    return cfg.exact && guided_radius >= 1 && guided_radius <= 4 && cfg.unit > 0.f;
+    return cfg.exact && guided_radius >= 1 && guided_radius <= 8 && guided_radius != 5 && cfg.unit > 0.f;
+}
+
+static int fast_tile_height(int guided_radius, bool w64) {
+    switch (guided_radius) {
+        case 1: return w64 ? FastTile<1, true>::TH : FastTile<1, false>::TH;
+        case 2: return w64 ? FastTile<2, true>::TH : FastTile<2, false>::TH;
+        case 3: return w64 ? FastTile<3, true>::TH : FastTile<3, false>::TH;
+        case 4: return w64 ? FastTile<4, true>::TH : FastTile<4, false>::TH;
+        case 6: return w64 ? FastTile<6, true>::TH : FastTile<6, false>::TH;
+        case 7: return w64 ? FastTile<7, true>::TH : FastTile<7, false>::TH;
+        case 8: return w64 ? FastTile<8, true>::TH : FastTile<8, false>::TH;
+        default: return 65;
+    }
 }
 
 // Number of disparity slices (gridDim.z) that gives the chip enough workgroups.
-int fused_fast_slices(int H, int W, int guided_radius, int n_disp) {
-    int tiles = ceil_div(W, 64 - 4 * guided_radius) * ceil_div(H, 65);
+int fused_fast_slices(int H, int W, int guided_radius, int n_disp, bool word64) {
+    int tiles = ceil_div(W, 64 - 4 * guided_radius) * ceil_div(H, fast_tile_height(guided_radius, word64));
+    const int nw = guided_radius >= 5 ? 8 : FF_NW;
     int s = 1;
     const char *e = getenv("STEREO_FAST_SLICES");
     if (e) return atoi(e) > 0 ? atoi(e) : 1;
-    while (tiles * s < 1024 && s * FF_NW * 4 <= n_disp) s *= 2;
+    while (tiles * s < 1024 && s * nw * 4 <= n_disp) s *= 2;
     return s;
 }
 
@@ -445,7 +468,10 @@ int launch_fused_guided_fast(const void *d_lw, const void *d_rw, const CensusCfg
         case 2: return w64 ? launch_fast_t<2, true>(a, s) : launch_fast_t<2, false>(a, s);
         case 3: return w64 ? launch_fast_t<3, true>(a, s) : launch_fast_t<3, false>(a, s);
         case 4: return w64 ? launch_fast_t<4, true>(a, s) : launch_fast_t<4, false>(a, s);
-        default: set_error("fast fused guided kernel supports radius 1..4"); return STEREO_EUNSUPPORTED;
+        case 6: return w64 ? launch_fast_t<6, true>(a, s) : launch_fast_t<6, false>(a, s);
+        case 7: return w64 ? launch_fast_t<7, true>(a, s) : launch_fast_t<7, false>(a, s);
+        case 8: return w64 ? launch_fast_t<8, true>(a, s) : launch_fast_t<8, false>(a, s);
+        default: set_error("one-column fused guided kernel supports radius 1..4 and 6..8"); return STEREO_EUNSUPPORTED;
     }
 }
 

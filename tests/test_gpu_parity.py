@@ -873,3 +873,28 @@ def test_guided_precompute_keeps_the_statistics_on_the_device(oracle):
         gc.collect()
     with pytest.raises(ValueError):
         gf.guided_filter_with_precompute(gf.prepare_guided_filter(left, 3, 0.0154), dsi[:10, :, 0])
+
+
+@pytest.mark.parametrize("rg,wct", [(6, 4), (7, 4), (8, 4), (6, 8), (7, 8), (8, 8)])
+@pytest.mark.parametrize("eps", [0.0154, 0.003])
+def test_guided_radius_6_to_8(oracle, rg, wct, eps):
+    """Guided radii 6 .. 8 (13- to 17-row windows): the one-column fused kernel for eps in the fast range, the general
+    float64 kernel below it -- both against the oracle, and the default choice against the general kernel."""
+    import stereo
+    from synth import synth_pair_gray
+    h, w, dmax = 170, 300, 20          # tiles away from every border exist for every radius
+    left, right, _ = synth_pair_gray(h, w, dmax, seed=rg * 10 + wct)
+    dsi = oracle.wct_cost_volume(left, right, dmax, radius=wct)
+    dref, cref, layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_GUIDED, rg, eps, want_layers=True)
+    run = lambda: stereo.compute_disparity(left, right, dmax, wct_radius=wct, guided_radius=rg, guided_eps=eps,
+                                           show_progress=False)
+    d, c = run()
+    assert_wta_matches(d, c, dref, cref, layers, min_agree=0.995)
+    d_gen, c_gen = _with_kernel(1, run)
+    assert rel_err(c, c_gen) <= 2e-6
+    # a disparity shard and dmax beyond the width go the same way
+    d2, c2 = stereo.compute_disparity(left, right, dmax, wct_radius=wct, guided_radius=rg, guided_eps=eps,
+                                      show_progress=False, d_begin=5, d_end=13)
+    dr2, cr2 = oracle.aggregate_and_wta(np.ascontiguousarray(dsi[:, :, 5:13]), left, oracle.FILTER_GUIDED, rg, eps)
+    dr2 = dr2 + np.where(np.isfinite(cr2), 5, 0).astype(np.int32)
+    assert rel_err(c2, cr2) <= TOL and np.mean(d2 == dr2) >= 0.995
