@@ -131,6 +131,9 @@ def parse_args():
                     help="guided eps (the benchmark's is 0.0154; smaller values time the kernels that serve them: "
                          "below 8e-3 the two-column kernel's precise variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-precise", action="store_true",
+                    help="skip the untimed steps with the all-float64 variant of the kernel (runs under a profiler: every "
+                         "launch of the dominant kernel is then a timed-variant launch)")
     ap.add_argument("--no-cpu-all-cores", action="store_true",
                     help="skip the second CPU figure (layers dealt to every core instead of the reference's threading)")
     ap.add_argument("--bands", type=int, default=0,
@@ -347,7 +350,7 @@ def main() -> None:
     # the all-float64 ("precise") variant of the dominant kernel on the same frame, a few untimed steps: the timed
     # variant mixes precisions (see "dtype"), and the line carries both figures
     precise_ms = None
-    if world == 1 and not use_dist and not two_call and args.filter == "guided" and n_bands == 1:
+    if world == 1 and not use_dist and not two_call and args.filter == "guided" and n_bands == 1 and not args.no_precise:
         _native.check(lib.stereo_debug_force_general_kernel(3))
         try:
             step()

@@ -52,8 +52,10 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void cost_unit_sample_kernel(const 
         bits |= (uint32_t)__shfl_xor((int)bits, off, 64);
         bad |= (uint32_t)__shfl_xor((int)bad, off, 64);
     }
+    // (atomics on one word serialise -- 32 000 wavefronts spent 0.37 ms on them: a wavefront reports only bits the
+    //  word does not hold yet; a stale read costs a needless atomic at worst)
     if ((threadIdx.x & 63) == 0) {
-        if (bits) atomicOr(&stats[3], bits);
+        if (bits & ~__hip_atomic_load(&stats[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&stats[3], bits);
         if (bad) atomicOr(&stats[4], 1u);
     }
 }

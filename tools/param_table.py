@@ -20,7 +20,9 @@ CASES = [
     ("guided r=1", dict(guided_radius=1, guided_eps=0.0154)),
     ("guided r=4", dict(guided_radius=4, guided_eps=0.0154)),
     ("guided r=5", dict(guided_radius=5, guided_eps=0.0154)),
-    ("guided r=6 (float64 fused kernel)", dict(guided_radius=6, guided_eps=0.0154)),
+    ("guided r=6 (one-column fused kernel)", dict(guided_radius=6, guided_eps=0.0154)),
+    ("guided r=8 (one-column fused kernel)", dict(guided_radius=8, guided_eps=0.0154)),
+    ("guided r=6 eps=0.003 (float64 fused kernel)", dict(guided_radius=6, guided_eps=0.003)),
     ("guided r=9 (no fused kernel)", dict(guided_radius=9, guided_eps=0.0154)),
     ("census radius 8, guided r=3", dict(wct_radius=8, guided_eps=0.0154)),
     ("base_weight 3.3 (weights not exactly summable), guided r=3", dict(base_weight=3.3, guided_eps=0.0154)),

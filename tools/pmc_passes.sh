@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name="$1"; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" -d "$OUT/$name" -o "$name" --output-format csv -- \
-      python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "${BENCH_ARGS[@]}" > "$OUT/$name.log" 2>&1
+      python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-precise "${BENCH_ARGS[@]}" > "$OUT/$name.log" 2>&1
   echo "pass $name done"
 }
 BENCH_ARGS=("$@")
