@@ -898,3 +898,21 @@ def test_guided_radius_6_to_8(oracle, rg, wct, eps):
     dr2, cr2 = oracle.aggregate_and_wta(np.ascontiguousarray(dsi[:, :, 5:13]), left, oracle.FILTER_GUIDED, rg, eps)
     dr2 = dr2 + np.where(np.isfinite(cr2), 5, 0).astype(np.int32)
     assert rel_err(c2, cr2) <= TOL and np.mean(d2 == dr2) >= 0.995
+
+
+def test_bilateral_against_the_reference_on_a_larger_frame(oracle):
+    """The bilateral pipeline against the reference's OWN result (tests/golden/make_golden_bilateral.py: the reference's
+    NumPy code on a 120 x 200 frame, 20 disparities).  Away from the left border -- where every window holds at least
+    one valid cost and exact ties between all-`large` layers cannot occur -- the disparities are identical on at least
+    99.9 % of the pixels; on the whole frame every difference is a near-tie in the oracle's layers."""
+    import stereo
+    g = load_golden("bilateral_120x200x20")
+    left, right, dmax = g["left"], g["right"], int(g["dmax"])
+    d, c = stereo.compute_disparity(left, right, dmax, filter_type="bilateral", bilateral_sigma=1.0, show_progress=False)
+    dsi = oracle.wct_cost_volume(left, right, dmax)
+    layers = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_BILATERAL, 0, 1.0, want_layers=True)[2]
+    assert_wta_matches(d, c, g["disp_bilateral"], g["cost_bilateral"], layers, min_agree=0.99)
+    inner = (slice(8, -8), slice(dmax + 8, -8))
+    agree = float(np.mean(d[inner] == g["disp_bilateral"][inner]))
+    print(f"bilateral against the reference, away from the borders: {agree:.6f}")
+    assert agree >= 0.999

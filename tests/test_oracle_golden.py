@@ -119,6 +119,20 @@ def test_filters_through_wta(oracle):
                       g["disp_bilateral"], g["cost_bilateral"], 2e-6) >= 0.95
 
 
+def test_bilateral_larger_frame(oracle):
+    """The reference's bilateral pipeline on a 120 x 200 frame (tests/golden/make_golden_bilateral.py): the oracle's
+    costs within 1e-6; its disparities identical away from the left border, and every difference near the border a
+    near-tie (libm's expf against NumPy's exp in the last place, on layers that are all `large` there)."""
+    g = load_golden("bilateral_120x200x20")
+    dmax = int(g["dmax"])
+    dsi = oracle.wct_cost_volume(g["left"], g["right"], dmax)
+    agree = _wta_close(oracle, dsi, g["left"], oracle.FILTER_BILATERAL, 0, 1.0, g["disp_bilateral"], g["cost_bilateral"], 2e-6)
+    assert agree >= 0.99
+    d = oracle.aggregate_and_wta(dsi, g["left"], oracle.FILTER_BILATERAL, 0, 1.0)[0]
+    inner = (slice(8, -8), slice(dmax + 8, -8))
+    assert np.mean(d[inner] == g["disp_bilateral"][inner]) >= 0.9999
+
+
 def test_radius8(oracle):
     g = load_golden("radius8_40x72x12")
     dsi = oracle.wct_cost_volume(g["left"], g["right"], 12, radius=8)
