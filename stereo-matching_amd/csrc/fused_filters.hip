@@ -2,11 +2,11 @@
 // bilateral aggregation filters: census cost -> filter -> running WTA in one kernel
 // (census.py:187-202, filters.py:139-224,279-310, stereo.py:145-170).
 //
-// A 256-thread workgroup owns a 16 x 64 pixel tile for the whole disparity range of the launch.
+// A 256-thread workgroup owns a 16 x 64 pixel tile (20 x 64 for the uint8 median) for the whole disparity range of the launch.
 // Every thread keeps the census word, the border-mapped coordinates and the validity of "its"
 // pixels of the tile + halo in registers; per disparity it writes their costs into one of two LDS
 // cost tiles (float32, or the quantised byte for the median), the workgroup synchronises once, and
-// every thread filters four vertically adjacent output pixels from that tile and updates their
+// every thread filters four (five) vertically adjacent output pixels from that tile and updates their
 // packed (cost, disparity) keys in registers.  Nothing but the final keys is written to HBM.
 //
 // The median needs the minimum and maximum of each unfiltered cost layer (filters.py:141-151)
@@ -24,7 +24,17 @@
 
 namespace shp {
 
-constexpr int FF_TW = 64, FF_TH = 16, FF_THREADS = 256, FF_ROWS_PER_THREAD = 4;
+constexpr int FF_TW = 64, FF_THREADS = 256;
+// Outputs per thread (vertically adjacent) and rows per tile.  Five rows per thread amortise the tile's halo and the
+// shared window rows better than four where the registers allow it (the uint8 median: 26.5 ms on a 7680 x 4320 frame
+// with 256 disparities against 27.3 with four and 28.7 with six); the float filters keep four.
+#ifndef FF_MEDIAN_RPT
+#define FF_MEDIAN_RPT 5
+#endif
+template <int FILTER> struct FFTile {
+    static constexpr int RPT = (FILTER == STEREO_FILTER_MEDIAN_U8Q) ? FF_MEDIAN_RPT : 4;
+    static constexpr int TH = 4 * RPT;
+};
 constexpr int FF_MAX_RADIUS = 8;
 #ifndef FF_BIL_UNROLL_MAX
 #define FF_BIL_UNROLL_MAX 2
@@ -64,18 +74,6 @@ __device__ __forceinline__ float ff_cost(const WordT *__restrict__ rw, const Cen
     const WordT rword = rw[ro + (ok ? xr : gx)];
     const float c = pair_cost<WordT>(lword, rword, cfg);
     return ok ? c : cfg.large;
-}
-
-// Exact median (scipy / vectorized / naive methods) of exactly summable census costs: the cost of a pixel in
-// integer units, or `code_large` (one above every valid cost) where the reference writes `large`.  The map from
-// codes to float32 costs is strictly increasing, so the median code is the code of the median cost.
-template <typename WordT>
-__device__ __forceinline__ uint32_t ff_code(const WordT *__restrict__ rw, const CensusCfg &cfg, WordT lword, bool lvalid,
-                                            int ro, int gx, int d, uint32_t code_large) {
-    const int xr = gx - d;
-    const bool ok = lvalid && xr >= cfg.radius;
-    const WordT rword = rw[ro + (ok ? xr : gx)];
-    return ok ? field_sum((WordT)(lword ^ rword)) : code_large;
 }
 
 // ---- pass 1 (median only): min / max of every cost layer ---------------------------------------
@@ -168,7 +166,9 @@ __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restric
 // formed once per column and disparity, the rows of a wavefront are addressed through scalar base pointers,
 // and `large` enters through one flag per lane (a pixel inside the image costs `large` iff it is invalid for
 // every disparity -- known before the loop -- or its column fails the column test).
-template <typename WordT>
+// HI_IS_LARGE: `large` is positive.  The first pixel of the frame is never a valid census centre, so every layer
+// holds `large`, which then exceeds every valid cost: the maximum needs no arithmetic.
+template <typename WordT, bool HI_IS_LARGE>
 __global__ __launch_bounds__(256) void cost_minmax_exact_kernel(const WordT *__restrict__ lw, const WordT *__restrict__ rw,
                                                                CensusCfg cfg, int H, int W, int d_begin, int d_end,
                                                                uint32_t *__restrict__ mm) {
@@ -231,13 +231,13 @@ __global__ __launch_bounds__(256) void cost_minmax_exact_kernel(const WordT *__r
                 const uint32_t u = field_sum((WordT)(lword[r][j] ^ rword));
                 const uint32_t m = vmask[r][j] & okx[j];
                 lo = min(lo, u | ~m);
-                hi = max(hi, u & m);
+                if (!HI_IS_LARGE) hi = max(hi, u & m);
             }
         }
         // units -> order-preserving float keys; a lane without a valid pixel keeps the neutral elements
         const bool none = lo == 0xffffffffu;
         lo = none ? lo : f32_to_ordered((float)lo * cfg.unit);
-        hi = (none && hi == 0u) ? 0u : f32_to_ordered((float)hi * cfg.unit);
+        hi = (HI_IS_LARGE || (none && hi == 0u)) ? 0u : f32_to_ordered((float)hi * cfg.unit);
         if (large_seen) { lo = min(lo, large_key); hi = max(hi, large_key); }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -276,12 +276,12 @@ __global__ void minmax_fill_kernel(uint32_t *mm, int n) {
     if (i < n) { mm[2 * i] = 0xffffffffu; mm[2 * i + 1] = 0u; }
 }
 
-// Medians of four vertically adjacent K x K windows of bytes (stored one per float slot, as integer
+// Medians of a thread's vertically adjacent K x K windows of bytes (stored one per float slot, as integer
 // bits) by bisection on the value: the median is the smallest m with count(window <= m) > K*K/2.
 // NPW = 32 / FB window elements share a 32-bit word in FB-bit fields holding (byte - tlo); with a
 // guard bit on top of each field, (m | guards) - word leaves the guard bit set exactly where the
 // element is <= m, so one subtract, one and, one popcount compare NPW elements with m.
-template <int K, int FB, int LW>
+template <int K, int FB, int LW, int FF_ROWS_PER_THREAD>
 __device__ __forceinline__ void median_bisect(const float *win, int tlo, int thi, int *med) {
     constexpr int NR = FF_ROWS_PER_THREAD + K - 1;
     constexpr int NPW = 32 / FB;
@@ -365,15 +365,22 @@ __device__ __forceinline__ void bs_count7(const uint32_t *m, uint32_t &b0, uint3
 constexpr int BS_CW = 72;  // row pitch of the column-count planes (70 columns used)
 
 // ---- pass 2: cost -> filter -> WTA ------------------------------------------------------------------
-template <int FILTER, bool WORD64, int RAD>
+// EXACT: the census weights are exactly summable (the cost is the integer field sum times the unit).  A template
+// parameter rather than a test of cfg.exact per pixel: with the branch inside the cost stage every load of a right
+// word was waited for before the next one was issued.
+template <int FILTER, bool WORD64, int RAD, bool EXACT>
 __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
     using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
+    constexpr int FF_ROWS_PER_THREAD = FFTile<FILTER>::RPT, FF_TH = FFTile<FILTER>::TH;
     constexpr int K = 2 * RAD + 1;
     constexpr int LW = FF_TW + 2 * RAD, LH = FF_TH + 2 * RAD, NP = LW * LH;
     constexpr int PT = (NP + FF_THREADS - 1) / FF_THREADS;   // halo pixels per thread
-    constexpr int NR = FF_ROWS_PER_THREAD + K - 1;           // tile rows one thread's four windows span
+    constexpr int NR = FF_ROWS_PER_THREAD + K - 1;           // tile rows one thread's windows span
     constexpr bool MEDIAN = FILTER == STEREO_FILTER_MEDIAN_U8Q;
-    constexpr bool MEDX = FILTER == STEREO_FILTER_MEDIAN;     // exact median on integer cost codes
+    // Exact median (scipy / vectorized / naive methods) of exactly summable census costs: the tile holds the cost of a
+    // pixel in integer units, or `code_large` (one above every valid cost) where the reference writes `large`.  The
+    // map from codes to float32 costs is strictly increasing, so the median code is the code of the median cost.
+    constexpr bool MEDX = FILTER == STEREO_FILTER_MEDIAN;
     __shared__ float cbuf[2][NP];
     // median: min / max byte of the cost tiles of disparities d, d + 1, d + 2 (slot = index mod 3); a slot is
     // reset two iterations before it is used, after the barrier that ends its last readers
@@ -448,32 +455,55 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
         }
         uint32_t *trange = trange_buf[(d - a.d_begin) % 3];
         uint32_t mylo = MEDX ? 2047u : 255u, myhi = 0u, my255 = 0u;
+        // The right words of all of this thread's pixels are requested before any of them is used, and the loop
+        // that uses them holds no branch that depends on the layer: the loads of one iteration are in flight together.
+        WordT rword[PT];
+        bool okv[PT];
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int xr = gxs[j] - d;
+            okv[j] = lvalid[j] && xr >= R;
+            rword[j] = rw[ro[j] + (okv[j] ? xr : gxs[j])];
+        }
+        // the last slot holds the few pixels beyond a multiple of the workgroup size: wavefronts whose lanes all
+        // lie beyond the tile skip its arithmetic
+        const bool last_slot_empty = (tid & ~63) + (PT - 1) * FF_THREADS >= NP;
+        uint32_t bytes[PT];
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const int idx = tid + j * FF_THREADS;
-            // the last slot holds the few pixels beyond a multiple of the workgroup size: wavefronts whose
-            // lanes all lie beyond the tile skip it
-            if (j == PT - 1 && (tid & ~63) + j * FF_THREADS >= NP) continue;
+            bytes[j] = 0u;
+            if (j == PT - 1 && last_slot_empty) continue;
+            const WordT x = lword[j] ^ rword[j];
             if (MEDX) {
-                const uint32_t e = ff_code<WordT>(rw, a.cfg, lword[j], lvalid[j], ro[j], gxs[j], d, a.code_large);
+                const uint32_t e = okv[j] ? field_sum(x) : a.code_large;
                 mylo = min(mylo, e);   // (a thread's surplus slot repeats a tile pixel)
                 myhi = max(myhi, e);
                 if (idx < NP) cb[idx] = __uint_as_float(e);
                 continue;
             }
-            float c = ff_cost<WordT>(rw, a.cfg, lword[j], lvalid[j], ro[j], gxs[j], d);
+            float c = EXACT ? (float)field_sum(x) * a.cfg.unit : sequential_cost<WordT>(x, a.cfg);
+            c = okv[j] ? c : a.cfg.large;
             if (MEDIAN) {
-                float s = (c - qlo) * qscale;
-                s = fminf(fmaxf(s, 0.f), 255.f);
-                const uint32_t b = flat ? 0u : (uint32_t)rintf(s);
-                if (!census_levels) {
-                    mylo = min(mylo, b);   // (a thread's surplus slot repeats a tile pixel)
-                    if (b == 255u) my255 = 1u; else myhi = max(myhi, b);
-                }
+                // filters.py:148-151 clips the scaled cost to [0, 255] before rounding.  Here every cost of the tile
+                // is a cost of the layer, so lo <= c <= hi with the layer's own lo and hi: c - lo >= 0, and the
+                // product with the float32 scale exceeds 255 by rounding only (it rounds to 255 either way).  A
+                // flat layer has scale 0 and finite costs: the product is 0.  Neither the clip nor a select is needed.
+                const uint32_t b = (uint32_t)rintf((c - qlo) * qscale);
+                bytes[j] = b;
                 c = __uint_as_float(b);
             }
             if (FILTER == STEREO_FILTER_BILATERAL) c *= a.vscale;
             if (idx < NP) cb[idx] = c;
+        }
+        if (MEDIAN && !census_levels) {
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                if (j == PT - 1 && last_slot_empty) continue;
+                const uint32_t b = bytes[j];
+                mylo = min(mylo, b);   // (a thread's surplus slot repeats a tile pixel)
+                if (b == 255u) my255 = 1u; else myhi = max(myhi, b);
+            }
         }
         if (MEDIAN && !census_levels) {
             // one LDS atomic triple per wavefront: (255 - min), max and the 255 flag travel through the lanes in one word
@@ -535,9 +565,9 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
         } else if (MEDX) {
             const int tlo = (int)trange[0], thi = max((int)trange[1], tlo);
             int med[FF_ROWS_PER_THREAD];
-            if (thi - tlo < 32) median_bisect<K, 6, LW>(win, tlo, thi, med);
-            else if (thi - tlo < 128) median_bisect<K, 8, LW>(win, tlo, thi, med);
-            else median_bisect<K, 12, LW>(win, tlo, thi, med);
+            if (thi - tlo < 32) median_bisect<K, 6, LW, FF_ROWS_PER_THREAD>(win, tlo, thi, med);
+            else if (thi - tlo < 128) median_bisect<K, 8, LW, FF_ROWS_PER_THREAD>(win, tlo, thi, med);
+            else median_bisect<K, 12, LW, FF_ROWS_PER_THREAD>(win, tlo, thi, med);
 #pragma unroll
             for (int j = 0; j < FF_ROWS_PER_THREAD; ++j)
                 outv[j] = (uint32_t)med[j] == a.code_large ? a.cfg.large : (float)med[j] * a.cfg.unit;
@@ -633,7 +663,7 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             int med[FF_ROWS_PER_THREAD];
             if (BITSLICED && thi2 - tlo <= 30 && !a.plain_median) {
                 // phase 1: 3-bit counts of the four 7-row column segments under this thread's outputs, for halo
-                // column lx; the six columns beyond 63 are taken by the first lanes of wavefront 0
+                // column lx; the six columns beyond 63 are taken by the first lanes of one wavefront
                 auto column_counts = [&](int c, int qq, auto census_tag) {
                     uint32_t m[NR];
 #pragma unroll
@@ -653,12 +683,16 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                         colcnt[2 * FF_TH * BS_CW + o] = b2;
                     }
                 };
+                // (the wavefront that takes the extra columns changes from tile to tile: the first wavefronts of
+                //  the workgroups that share a compute unit would otherwise all load the same SIMD)
+                const int xt = tid - 64 * (int)((blockIdx.x + blockIdx.y) & 3u);
+                const bool extra = xt >= 0 && xt < 4 * (LW - FF_TW);
                 if (census_levels) {
                     column_counts(lx, q, std::true_type{});
-                    if (tid < 4 * (LW - FF_TW)) column_counts(FF_TW + tid % (LW - FF_TW), tid / (LW - FF_TW), std::true_type{});
+                    if (extra) column_counts(FF_TW + xt % (LW - FF_TW), xt / (LW - FF_TW), std::true_type{});
                 } else {
                     column_counts(lx, q, std::false_type{});
-                    if (tid < 4 * (LW - FF_TW)) column_counts(FF_TW + tid % (LW - FF_TW), tid / (LW - FF_TW), std::false_type{});
+                    if (extra) column_counts(FF_TW + xt % (LW - FF_TW), xt / (LW - FF_TW), std::false_type{});
                 }
                 __syncthreads();
                 // phase 2: add the seven columns of each window, find the first level with count >= 25
@@ -706,9 +740,9 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                     med[j] = lo;
                 }
             } else if (thi - tlo < 32) {
-                median_bisect<K, 6, LW>(win, tlo, thi, med);
+                median_bisect<K, 6, LW, FF_ROWS_PER_THREAD>(win, tlo, thi, med);
             } else {
-                median_bisect<K, 10, LW>(win, tlo, thi, med);
+                median_bisect<K, 10, LW, FF_ROWS_PER_THREAD>(win, tlo, thi, med);
             }
 #pragma unroll
             for (int j = 0; j < FF_ROWS_PER_THREAD; ++j)
@@ -741,8 +775,12 @@ size_t fused_filter_minmax_bytes(int n_disp) { return (size_t)n_disp * 8; }
 
 template <int FILTER, bool WORD64, int RAD>
 static int launch_ff(const FFArgs &a, hipStream_t s) {
-    dim3 grid(ceil_div(a.W, FF_TW), ceil_div(a.H, FF_TH));
-    hipLaunchKernelGGL((fused_filter_kernel<FILTER, WORD64, RAD>), grid, dim3(FF_THREADS), 0, s, a);
+    dim3 grid(ceil_div(a.W, FF_TW), ceil_div(a.H, FFTile<FILTER>::TH));
+    // (the exact median works on integer codes: it has one form only)
+    if (a.cfg.exact && a.cfg.unit > 0.f && FILTER != STEREO_FILTER_MEDIAN)
+        hipLaunchKernelGGL((fused_filter_kernel<FILTER, WORD64, RAD, true>), grid, dim3(FF_THREADS), 0, s, a);
+    else
+        hipLaunchKernelGGL((fused_filter_kernel<FILTER, WORD64, RAD, false>), grid, dim3(FF_THREADS), 0, s, a);
     SHP_LAUNCH_CHECK();
     return STEREO_OK;
 }
@@ -813,12 +851,15 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
             SHP_LAUNCH_CHECK();
             dim3 grid(ceil_div(W, 64 * 8), ceil_div(H, 4 * MM_ROWS));
             const bool exact = cfg.exact && cfg.unit > 0.f;
+            const bool hil = cfg.large > 0.f;
             if (cfg.word64) {
-                auto kern = exact ? cost_minmax_exact_kernel<uint64_t> : cost_minmax_kernel<uint64_t>;
+                auto kern = exact ? (hil ? cost_minmax_exact_kernel<uint64_t, true> : cost_minmax_exact_kernel<uint64_t, false>)
+                                  : cost_minmax_kernel<uint64_t>;
                 hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, static_cast<const uint64_t *>(d_lw),
                                    static_cast<const uint64_t *>(d_rw), cfg, H, W, d_begin, d_end, d_mm);
             } else {
-                auto kern = exact ? cost_minmax_exact_kernel<uint32_t> : cost_minmax_kernel<uint32_t>;
+                auto kern = exact ? (hil ? cost_minmax_exact_kernel<uint32_t, true> : cost_minmax_exact_kernel<uint32_t, false>)
+                                  : cost_minmax_kernel<uint32_t>;
                 hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, static_cast<const uint32_t *>(d_lw),
                                    static_cast<const uint32_t *>(d_rw), cfg, H, W, d_begin, d_end, d_mm);
             }
