@@ -31,8 +31,14 @@ constexpr int FF_TW = 64, FF_THREADS = 256;
 #ifndef FF_MEDIAN_RPT
 #define FF_MEDIAN_RPT 5
 #endif
+#ifndef FF_GAUSS_RPT
+#define FF_GAUSS_RPT 6
+#endif
+#ifndef FF_MEDX_RPT
+#define FF_MEDX_RPT 4
+#endif
 template <int FILTER> struct FFTile {
-    static constexpr int RPT = (FILTER == STEREO_FILTER_MEDIAN_U8Q) ? FF_MEDIAN_RPT : 4;
+    static constexpr int RPT = (FILTER == STEREO_FILTER_MEDIAN_U8Q) ? FF_MEDIAN_RPT : (FILTER == STEREO_FILTER_GAUSSIAN) ? FF_GAUSS_RPT : (FILTER == STEREO_FILTER_MEDIAN) ? FF_MEDX_RPT : 4;
     static constexpr int TH = 4 * RPT;
 };
 constexpr int FF_MAX_RADIUS = 8;
@@ -397,8 +403,10 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
 
     // this thread's pixels of the tile + halo, with the filter's border rule applied
     WordT lword[PT];
-    int ro[PT], gxs[PT];
-    bool lvalid[PT];
+    // byte offset of the pixel's own right word, and the largest disparity at which the pair is valid (-1: the
+    // left pixel is no valid census centre): the pair (x, x - d) is valid iff d <= x - R.
+    uint32_t boff[PT];
+    int dlim[PT];
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
         const int idx = min(tid + j * FF_THREADS, NP - 1);
@@ -406,10 +414,9 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
         int gy = y0 - RAD + ly, gx = x0 - RAD + lx;
         if (MEDIAN || MEDX) { gy = min(max(gy, 0), H - 1); gx = min(max(gx, 0), W - 1); }   // replicate (cv2.medianBlur, scipy mode="nearest")
         else { gy = ff_reflect101(gy, H); gx = ff_reflect101(gx, W); }               // reflect-101
-        ro[j] = gy * W;
-        gxs[j] = gx;
-        lword[j] = lw[ro[j] + gx];
-        lvalid[j] = gy >= R && gy < H - R && gx >= R && gx < W - R;
+        lword[j] = lw[gy * W + gx];
+        boff[j] = (uint32_t)(gy * W + gx) * (uint32_t)sizeof(WordT);
+        dlim[j] = (gy >= R && gy < H - R && gx >= R && gx < W - R) ? gx - R : -1;
     }
 
     const int lx = tid & 63, q = tid >> 6;
@@ -461,9 +468,10 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
         bool okv[PT];
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-            const int xr = gxs[j] - d;
-            okv[j] = lvalid[j] && xr >= R;
-            rword[j] = rw[ro[j] + (okv[j] ? xr : gxs[j])];
+            okv[j] = d <= dlim[j];
+            // (an invalid pair reads some word of the image: the subtraction saturates at the first one)
+            const uint32_t o = __builtin_elementwise_sub_sat(boff[j], (uint32_t)d * (uint32_t)sizeof(WordT));
+            rword[j] = *reinterpret_cast<const WordT *>(reinterpret_cast<const char *>(rw) + o);
         }
         // the last slot holds the few pixels beyond a multiple of the workgroup size: wavefronts whose lanes all
         // lie beyond the tile skip its arithmetic
@@ -809,7 +817,8 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
                         hipStream_t s, bool plain_median) {
     if (H <= 0 || W <= 0) return STEREO_OK;
     if (!fused_filter_supported(filter_kind, radius)) { set_error("unsupported fused filter"); return STEREO_EUNSUPPORTED; }
-    if ((size_t)H * W > 0x7fffffffu) { set_error("image too large for the fused filter kernels"); return STEREO_EUNSUPPORTED; }
+    // (the kernels address the census words by 32-bit byte offsets)
+    if ((size_t)H * W * 8 > 0xffffffffu) { set_error("image too large for the fused filter kernels"); return STEREO_EUNSUPPORTED; }
     if (d_begin >= d_end) return launch_fill_keys(d_keys, (size_t)H * W, s);
     FFArgs a;
     memset(&a, 0, sizeof(a));
