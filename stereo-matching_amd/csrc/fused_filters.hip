@@ -82,6 +82,25 @@ __device__ __forceinline__ float ff_cost(const WordT *__restrict__ rw, const Cen
     return ok ? c : cfg.large;
 }
 
+// Minimum / maximum over the 64 lanes of a wavefront (every lane active), the same value in every lane: four
+// data-parallel-primitive steps inside each row of 16 lanes, then the four rows through scalar registers.  (The
+// butterfly of lane permutations this replaces goes through the LDS crossbar, about a hundred cycles a step, six
+// dependent steps per reduction: with two wavefronts per SIMD that latency was most of the range pass.)
+template <int CTRL>
+__device__ __forceinline__ uint32_t ff_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, ff_dpp<0xB1>(v));    // quad_perm [1, 0, 3, 2]
+    v = min(v, ff_dpp<0x4E>(v));    // quad_perm [2, 3, 0, 1]
+    v = min(v, ff_dpp<0x141>(v));   // row_half_mirror
+    v = min(v, ff_dpp<0x140>(v));   // row_mirror
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+
 // ---- pass 1 (median only): min / max of every cost layer ---------------------------------------
 // One wavefront owns MM_ROWS rows x 512 columns: 8 x MM_ROWS pixels per lane whose left words stay in
 // registers over the disparity loop, so that the wavefront-wide reduction and the two global atomics
@@ -130,12 +149,7 @@ __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restric
                 if (in) { lo = min(lo, k); hi = max(hi, k); }
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
-            hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
-        }
-        lo_out = lo; hi_out = hi;
+        lo_out = wave_min_u32(lo); hi_out = wave_max_u32(hi);
     };
     // The per-disparity results of a wavefront are parked in LDS and merged into the global table once per
     // MM_CHUNK disparities by all lanes at once: the disparity loop then holds no global read-modify-write whose
@@ -169,35 +183,43 @@ __global__ __launch_bounds__(256) void cost_minmax_kernel(const WordT *__restric
 
 // The same pass for exactly summable weights (the cost is an integer number of units), written without
 // branches or per-pixel selects: validity travels as all-ones / all-zero masks, the column test x - d >= radius is
-// formed once per column and disparity, the rows of a wavefront are addressed through scalar base pointers,
-// and `large` enters through one flag per lane (a pixel inside the image costs `large` iff it is invalid for
-// every disparity -- known before the loop -- or its column fails the column test).
+// formed once per column and disparity, and `large` enters through one flag per lane (a pixel inside the image
+// costs `large` iff it is invalid for every disparity -- known before the loop -- or its column fails the column test).
+// The right words come from LDS: a workgroup (8 rows x 512 columns) stages, for MM_CHUNK disparities at a time, the
+// words of its rows from MM_CHUNK - 1 columns left of the tile to its last column, and every disparity of the chunk
+// reads them from there.  Read from global memory instead, the words were fetched from HBM again every few
+// disparities (21.7 GB per launch on a 7680 x 4320 frame with 256 disparities: the wavefronts of a compute unit
+// touch 128 KB per disparity, four times its vector cache, and those of an XCD all of its L2).
 // HI_IS_LARGE: `large` is positive.  The first pixel of the frame is never a valid census centre, so every layer
 // holds `large`, which then exceeds every valid cost: the maximum needs no arithmetic.
+constexpr int MMX_ROWS = 2;                   // rows per wavefront
+constexpr int MMX_COLS = 512;                 // columns per workgroup
+constexpr int MMX_LW = MMX_COLS + MM_CHUNK;   // right words per staged row
 template <typename WordT, bool HI_IS_LARGE>
 __global__ __launch_bounds__(256) void cost_minmax_exact_kernel(const WordT *__restrict__ lw, const WordT *__restrict__ rw,
                                                                CensusCfg cfg, int H, int W, int d_begin, int d_end,
                                                                uint32_t *__restrict__ mm) {
-    constexpr int PPT = 8;  // pixels per lane and row: columns x0 + lane + 64 j
+    constexpr int PPT = MMX_COLS / 64;  // pixels per lane and row: columns x0 + lane + 64 j
+    __shared__ WordT rtile[4 * MMX_ROWS][MMX_LW];
+    __shared__ uint32_t parked[4][2][MM_CHUNK];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int y0 = ((int)blockIdx.y * 4 + wave) * MM_ROWS;
-    const int x0 = blockIdx.x * (64 * PPT);
-    if (y0 >= H) return;
+    const int yb = (int)blockIdx.y * 4 * MMX_ROWS;   // first row of the workgroup (inside the image)
+    const int y0 = yb + wave * MMX_ROWS;              // first row of the wavefront (may lie below the image)
+    const int x0 = blockIdx.x * MMX_COLS;
+    const int x_last = min(x0 + MMX_COLS - 1, W - 1);
     const int R = cfg.radius;
-    WordT lword[MM_ROWS][PPT];
-    uint32_t vmask[MM_ROWS][PPT];      // all ones: left census centre valid and the pixel inside the image
+    WordT lword[MMX_ROWS][PPT];
+    uint32_t vmask[MMX_ROWS][PPT];     // all ones: left census centre valid and the pixel inside the image
     uint32_t col_inside[PPT];          // all ones: some row of the column lies inside the image
     int xcol[PPT];
-    const WordT *rrow[MM_ROWS];
     uint32_t const_large = 0u;         // all ones: some pixel of this lane is inside the image and never valid
 #pragma unroll
     for (int j = 0; j < PPT; ++j) { col_inside[j] = 0u; xcol[j] = min(x0 + lane + 64 * j, W - 1); }
 #pragma unroll
-    for (int r = 0; r < MM_ROWS; ++r) {
+    for (int r = 0; r < MMX_ROWS; ++r) {
         const int y = min(y0 + r, H - 1);
         const bool yin = y0 + r < H, yvalid = y >= R && y < H - R;
-        rrow[r] = rw + (size_t)y * W;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const int x = x0 + lane + 64 * j;
@@ -212,30 +234,40 @@ __global__ __launch_bounds__(256) void cost_minmax_exact_kernel(const WordT *__r
     // the masks live in vector registers from here on (left to itself the compiler turns them back into lane
     // masks in scalar registers, runs out of those, and spills them through v_writelane / v_readlane)
 #pragma unroll
-    for (int r = 0; r < MM_ROWS; ++r)
+    for (int r = 0; r < MMX_ROWS; ++r)
 #pragma unroll
         for (int j = 0; j < PPT; ++j) asm volatile("" : "+v"(vmask[r][j]));
 #pragma unroll
     for (int j = 0; j < PPT; ++j) asm volatile("" : "+v"(col_inside[j]));
     asm volatile("" : "+v"(const_large));
     const uint32_t large_key = f32_to_ordered(cfg.large);
-    auto layer_range = [&](int d, uint32_t &lo_out, uint32_t &hi_out) {
-        uint32_t lo = 0xffffffffu, hi = 0u, large_seen = const_large;
-        uint32_t okx[PPT], boff[PPT];
+    uint32_t boff[PPT];   // byte offset of the column's own word within a staged row
+    const char *myrows = reinterpret_cast<const char *>(&rtile[wave * MMX_ROWS][0]);
+    // One layer in two steps, so that the staged words of the next layer can be requested before the arithmetic of
+    // this one (with two wavefronts per SIMD the LDS latency is not hidden otherwise): read_layer fetches the right
+    // words of disparity dc + dl (chunk at dc), layer_range reduces them.
+    auto read_layer = [&](int dl, WordT (&rword)[MMX_ROWS][PPT]) {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            const int t = xcol[j] - d;
-            okx[j] = (uint32_t)((R - 1 - t) >> 31);                    // all ones iff t >= R
-            boff[j] = (uint32_t)max(t, 0) * (uint32_t)sizeof(WordT);   // (a column that fails the test reads any word)
-            large_seen |= col_inside[j] & ~okx[j];
+            // (the staged row starts at column 0 or at the leftmost column the chunk reads: a column that fails the
+            //  column test reads some staged word)
+            const uint32_t o = __builtin_elementwise_sub_sat(boff[j], (uint32_t)dl * (uint32_t)sizeof(WordT));
+#pragma unroll
+            for (int r = 0; r < MMX_ROWS; ++r)
+                rword[r][j] = *reinterpret_cast<const WordT *>(myrows + r * (MMX_LW * (int)sizeof(WordT)) + o);
         }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto layer_range = [&](int d, const WordT (&rword)[MMX_ROWS][PPT], uint32_t &lo_out, uint32_t &hi_out) {
+        uint32_t lo = 0xffffffffu, hi = 0u, large_seen = const_large;
 #pragma unroll
-        for (int r = 0; r < MM_ROWS; ++r) {
+        for (int j = 0; j < PPT; ++j) {
+            const uint32_t okx = (uint32_t)((R - 1 - (xcol[j] - d)) >> 31);   // all ones iff x - d >= R
+            large_seen |= col_inside[j] & ~okx;
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const WordT rword = *reinterpret_cast<const WordT *>(reinterpret_cast<const char *>(rrow[r]) + boff[j]);
-                const uint32_t u = field_sum((WordT)(lword[r][j] ^ rword));
-                const uint32_t m = vmask[r][j] & okx[j];
+            for (int r = 0; r < MMX_ROWS; ++r) {
+                const uint32_t u = field_sum((WordT)(lword[r][j] ^ rword[r][j]));
+                const uint32_t m = vmask[r][j] & okx;
                 lo = min(lo, u | ~m);
                 if (!HI_IS_LARGE) hi = max(hi, u & m);
             }
@@ -245,21 +277,33 @@ __global__ __launch_bounds__(256) void cost_minmax_exact_kernel(const WordT *__r
         lo = none ? lo : f32_to_ordered((float)lo * cfg.unit);
         hi = (HI_IS_LARGE || (none && hi == 0u)) ? 0u : f32_to_ordered((float)hi * cfg.unit);
         if (large_seen) { lo = min(lo, large_key); hi = max(hi, large_key); }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
-            hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
-        }
-        lo_out = lo; hi_out = hi;
+        lo_out = wave_min_u32(lo); hi_out = wave_max_u32(hi);
+        __builtin_amdgcn_sched_barrier(0);
     };
-    __shared__ uint32_t parked[4][2][MM_CHUNK];
     uint32_t (*mine)[MM_CHUNK] = parked[wave];
     for (int dc = d_begin; dc < d_end; dc += MM_CHUNK) {
         const int n = min(MM_CHUNK, d_end - dc);
+        // stage the columns the chunk reads, x - d for the tile's x and the chunk's d clamped at the first column:
+        // xb .. xe of the workgroup's rows (rows below the image repeat the last one)
+        const int xb = max(x0 - dc - (n - 1), 0);
+        const int xe = max(x_last - dc, xb);
+        const int width = xe - xb + 1;       // <= MMX_COLS + n - 1 < MMX_LW
+        __syncthreads();                     // (the previous chunk's readers are done)
+        for (int i = threadIdx.x; i < 4 * MMX_ROWS * MMX_LW; i += 256) {
+            const int row = i / MMX_LW, c = i - row * MMX_LW;
+            if (c < width) rtile[row][c] = rw[(size_t)min(yb + row, H - 1) * W + xb + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) boff[j] = (uint32_t)max(xcol[j] - dc - xb, 0) * (uint32_t)sizeof(WordT);
+        WordT rw_a[MMX_ROWS][PPT], rw_b[MMX_ROWS][PPT];
+        read_layer(0, rw_a);
         for (int i = 0; i < n; i += 2) {
             uint32_t lo0, hi0, lo1 = 0xffffffffu, hi1 = 0u;
-            layer_range(dc + i, lo0, hi0);
-            if (i + 1 < n) layer_range(dc + i + 1, lo1, hi1);
+            read_layer(min(i + 1, n - 1), rw_b);
+            layer_range(dc + i, rw_a, lo0, hi0);
+            read_layer(min(i + 2, n - 1), rw_a);
+            if (i + 1 < n) layer_range(dc + i + 1, rw_b, lo1, hi1);
             if (lane == 0) {
                 mine[0][i] = lo0; mine[1][i] = hi0;
                 if (i + 1 < n) { mine[0][i + 1] = lo1; mine[1][i + 1] = hi1; }
@@ -858,8 +902,8 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
             const int nd = d_end - d_begin;
             hipLaunchKernelGGL(minmax_fill_kernel, dim3(ceil_div(nd, 256)), dim3(256), 0, s, d_mm, nd);
             SHP_LAUNCH_CHECK();
-            dim3 grid(ceil_div(W, 64 * 8), ceil_div(H, 4 * MM_ROWS));
             const bool exact = cfg.exact && cfg.unit > 0.f;
+            dim3 grid(ceil_div(W, 64 * 8), ceil_div(H, 4 * (exact ? MMX_ROWS : MM_ROWS)));
             const bool hil = cfg.large > 0.f;
             if (cfg.word64) {
                 auto kern = exact ? (hil ? cost_minmax_exact_kernel<uint64_t, true> : cost_minmax_exact_kernel<uint64_t, false>)

@@ -780,6 +780,23 @@ def test_fused_median_rescale_rounds_twice(oracle):
     assert np.array_equal(d, dref) and np.array_equal(c, cref)
 
 
+@pytest.mark.parametrize("wct_radius,w,dmax,d0,d1", [(4, 700, 300, 0, 300), (8, 600, 280, 3, 277), (4, 530, 600, 250, 600)])
+def test_fused_median_range_pass_across_tiles_and_chunks(oracle, wct_radius, w, dmax, d0, d1):
+    """The range pass of the uint8 median stages the right census words of a 512-column tile in LDS for 256
+    disparities at a time: frames wider than a tile, more disparities than a chunk, a range that starts inside
+    a chunk, disparities above the width of the first tile.  Bit-exact against the oracle."""
+    import stereo
+    from synth import synth_pair_gray
+    h = 21
+    left, right, _ = synth_pair_gray(h, w, min(dmax, 200), seed=77 + w)
+    dsi = oracle.wct_cost_volume(left, right, dmax, radius=wct_radius)
+    dref, cref = oracle.aggregate_and_wta(np.ascontiguousarray(dsi[:, :, d0:d1]), left, oracle.FILTER_MEDIAN_U8Q, 3, 0.0)
+    dref = dref + np.where(np.isfinite(cref), d0, 0).astype(np.int32)
+    d, c = stereo.compute_disparity(left, right, dmax, wct_radius=wct_radius, filter_type="median", show_progress=False,
+                                    d_begin=d0, d_end=d1)
+    assert np.array_equal(d, dref) and np.array_equal(c, cref)
+
+
 def test_guided_eps_is_judged_against_the_guide_range(oracle):
     """A uint8 image as guide (values 0..255 instead of 0..1) makes eps = 0.02 tiny against the guide's variance:
     the float32 second stage of the fast kernels would be off by more than 1e-5 of a cost unit here.  The choice

@@ -21,7 +21,7 @@ def main() -> None:
 
     for name in ("bench_line.json", "bench_single_rank_rccl_overlap.json", "two_call_bench_line.json",
                  "config4_4k_bench_line.json", "param_table.txt", "eps_0.005.json", "eps_0.0001.json",
-                 "precompute_loop.txt", "shard_compute.txt"):
+                 "precompute_loop.txt", "shard_compute.txt", "shard_compute_4k.txt"):
         copy(name, name)
     copy("pair.json", "pair_bench_under_rocprof.json")
     for f in ("guided", "median", "gaussian", "bilateral"):
@@ -43,7 +43,7 @@ def main() -> None:
     # counter passes
     copy(os.path.join("pmc_pair", "pmc_per_launch.json"), "pair_pmc_per_launch.json")
     copy(os.path.join("pmc_two_call", "pmc_per_launch.json"), "two_call_pmc_per_launch.json")
-    for f in ("bilateral", "median"):
+    for f in ("bilateral", "median", "gaussian"):
         copy(os.path.join(f"pmc_{f}", "pmc_per_launch.json"), os.path.join("config5", f"{f}_pmc_per_launch.json"))
     print("collected into", dst)
 

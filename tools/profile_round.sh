@@ -35,7 +35,7 @@ for f in guided median gaussian bilateral; do
   timeout -k 10 300 python bench.py --workload 8k --filter $f --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/config5_${f}_8k_bench_line.json" 2> "$OUT/8k_$f.err" || exit 1
   trace config5_$f --workload 8k --filter $f --steps 3 --warmup 1 || exit 1
 done
-for f in median bilateral; do
+for f in median bilateral gaussian; do
   timeout -k 10 600 bash tools/pmc_passes.sh "$R/pmc_$f" --workload 8k --filter $f > "$OUT/pmc_$f.log" 2>&1 || exit 1
 done
 # 7. the precise variant, the per-layer operator loop, the parameter table, the shard floor
@@ -45,4 +45,5 @@ done
 timeout -k 10 200 python tools/precompute_loop.py 270 > "$OUT/precompute_loop.txt" 2> "$OUT/precompute_loop.err" || exit 1
 timeout -k 10 600 python tools/param_table.py > "$OUT/param_table.txt" 2> "$OUT/param_table.err" || exit 1
 timeout -k 10 400 python tools/shard_compute.py > "$OUT/shard_compute.txt" 2> "$OUT/shard_compute.err" || echo "shard_compute failed"
+timeout -k 10 400 python tools/shard_compute.py 4k > "$OUT/shard_compute_4k.txt" 2> "$OUT/shard_compute_4k.err" || echo "shard_compute 4k failed"
 echo done
