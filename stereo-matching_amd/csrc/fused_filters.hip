@@ -558,32 +558,22 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             }
         }
         if (MEDIAN && !census_levels) {
-            // one LDS atomic triple per wavefront: (255 - min), max and the 255 flag travel through the lanes in one word
-            uint32_t nlo = 255u - mylo;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t other = (uint32_t)__shfl_xor((int)((my255 << 16) | (nlo << 8) | myhi), off, 64);
-                my255 |= other >> 16;
-                nlo = max(nlo, (other >> 8) & 255u);
-                myhi = max(myhi, other & 255u);
-            }
+            // one LDS atomic triple per wavefront
+            mylo = wave_min_u32(mylo);
+            myhi = wave_max_u32(myhi);
+            my255 = wave_max_u32(my255);
             if ((tid & 63) == 0) {
-                atomicMin(&trange[0], 255u - nlo);
+                atomicMin(&trange[0], mylo);
                 atomicMax(&trange[1], myhi);
                 if (my255) atomicOr(&trange[2], 1u);
             }
         }
         if (MEDX) {
-            // range of the tile's codes: (2047 - min) and max travel through the lanes in one word
-            uint32_t nlo = 2047u - mylo;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t other = (uint32_t)__shfl_xor((int)((nlo << 11) | myhi), off, 64);
-                nlo = max(nlo, other >> 11);
-                myhi = max(myhi, other & 2047u);
-            }
+            // range of the tile's codes
+            mylo = wave_min_u32(mylo);
+            myhi = wave_max_u32(myhi);
             if ((tid & 63) == 0) {
-                atomicMin(&trange[0], 2047u - nlo);
+                atomicMin(&trange[0], mylo);
                 atomicMax(&trange[1], myhi);
             }
         }
