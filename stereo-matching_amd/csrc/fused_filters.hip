@@ -389,30 +389,84 @@ __device__ __forceinline__ void median_bisect(const float *win, int tlo, int thi
     }
 }
 
-// ---- bit-sliced counting median (7 x 7 windows whose bytes span fewer than 32 levels) --------------
+// ---- bit-sliced counting median (K x K windows whose bytes span fewer than 32 levels) --------------
 // A byte b of the tile becomes the 32-bit mask of the levels t >= v, v = b - tlo (255, the quantised
 // `large`, takes level 31, which no other byte reaches).  Bit t of a mask says "this element is <= level
 // t", so adding masks bit position by bit position counts, for all 32 levels at once, the elements not
 // above each level.  The additions are carry-save adders on whole words (two three-input logic
-// instructions each): 7 masks of a column -> a 3-bit count per level held in three words; 7 such
-// columns -> a 6-bit count per level; the word of the predicate "count >= 25" has its lowest set bit at
-// the median level.  Column counts are shared through LDS by the seven windows that contain the column.
+// instructions each): K masks of a column -> a count per level held in bs_bits(K) words (7 -> 3); K such
+// columns -> the count of the window (49 -> 6 bits); the word of the predicate "count >= K * K / 2 + 1" has its
+// lowest set bit at the median level.  Column counts are shared through LDS by the K windows that contain the column.
 // (written as the three-input logic instruction with its truth table: from the C expressions the compiler forms
 //  it for some of the adders only and spends two or three instructions on the others)
 __device__ __forceinline__ uint32_t bs_xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 __device__ __forceinline__ uint32_t bs_maj3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
 __device__ __forceinline__ uint32_t bs_or3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE); }
 __device__ __forceinline__ uint32_t bs_and3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x80); }
-// seven one-bit words -> their 3-bit sum (b0 + 2 b1 + 4 b2)
-__device__ __forceinline__ void bs_count7(const uint32_t *m, uint32_t &b0, uint32_t &b1, uint32_t &b2) {
-    const uint32_t x1 = bs_xor3(m[0], m[1], m[2]), y1 = bs_maj3(m[0], m[1], m[2]);
-    const uint32_t x2 = bs_xor3(m[3], m[4], m[5]), y2 = bs_maj3(m[3], m[4], m[5]);
-    b0 = bs_xor3(x1, x2, m[6]);
-    const uint32_t y3 = bs_maj3(x1, x2, m[6]);
-    b1 = bs_xor3(y1, y2, y3);
-    b2 = bs_maj3(y1, y2, y3);
+// number of bits that hold n
+constexpr int bs_bits(int n) { int b = 0; while (n) { ++b; n >>= 1; } return b; }
+// N one-bit words of equal weight -> the bit planes of their sum, out[0 .. bs_bits(N)): a chain of full adders leaves
+// one word of this weight and N / 2 carries of the next, which are summed the same way.
+template <int N>
+__device__ __forceinline__ void bs_sum(const uint32_t *w, uint32_t *out) {
+    if constexpr (N == 1) {
+        out[0] = w[0];
+    } else {
+        constexpr int F = (N - 1) / 2, C = N / 2;
+        uint32_t carry[C];
+        uint32_t acc = w[0];
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            carry[i] = bs_maj3(acc, w[2 * i + 1], w[2 * i + 2]);
+            acc = bs_xor3(acc, w[2 * i + 1], w[2 * i + 2]);
+        }
+        if (N % 2 == 0) { carry[F] = acc & w[N - 1]; acc ^= w[N - 1]; }
+        out[0] = acc;
+        bs_sum<C>(carry, out + 1);
+    }
 }
-constexpr int BS_CW = 72;  // row pitch of the column-count planes (70 columns used)
+// Bit planes s[W .. NB2) of S = sum over p of 2^p U_p, where U_p has the bit planes u[p][0 .. NB1): weight by weight,
+// the planes of that weight and the NC carries of the weight below go through a chain of full adders.  (S fits NB2
+// bits, so the carries out of the last weight are zero and dropped.)
+template <int NB1, int NB2, int W, int NC>
+__device__ __forceinline__ void bs_weighted_sum(const uint32_t (&u)[NB1][NB1], const uint32_t *cin, uint32_t *s) {
+    if constexpr (W < NB2) {
+        constexpr int P0 = W - (NB1 - 1) > 0 ? W - (NB1 - 1) : 0, P1 = W < NB1 - 1 ? W : NB1 - 1;
+        constexpr int NIN = P1 >= P0 ? P1 - P0 + 1 : 0, N = NIN + NC;
+        if constexpr (N == 0) {
+            s[W] = 0u;
+            bs_weighted_sum<NB1, NB2, W + 1, 0>(u, cin, s);
+        } else {
+            uint32_t w[N];
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) w[i] = u[P0 + i][W - P0 - i];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) w[NIN + i] = cin[i];
+            constexpr int F = (N - 1) / 2, C = N / 2;
+            uint32_t carry[C > 0 ? C : 1];
+            uint32_t acc = w[0];
+#pragma unroll
+            for (int i = 0; i < F; ++i) {
+                carry[i] = bs_maj3(acc, w[2 * i + 1], w[2 * i + 2]);
+                acc = bs_xor3(acc, w[2 * i + 1], w[2 * i + 2]);
+            }
+            if (N > 1 && N % 2 == 0) { carry[F] = acc & w[N - 1]; acc ^= w[N - 1]; }
+            s[W] = acc;
+            bs_weighted_sum<NB1, NB2, W + 1, C>(u, carry, s);
+        }
+    }
+}
+// the word of the predicate S >= T for the bit planes s[0 .. NB) of S (T < 2^NB)
+template <int NB, int T>
+__device__ __forceinline__ uint32_t bs_at_least(const uint32_t *s) {
+    uint32_t ge = 0u, eq = 0xffffffffu;
+#pragma unroll
+    for (int b = NB - 1; b >= 0; --b) {
+        if ((T >> b) & 1) eq &= s[b];
+        else { ge |= eq & s[b]; eq &= ~s[b]; }
+    }
+    return ge | eq;
+}
 
 // ---- pass 2: cost -> filter -> WTA ------------------------------------------------------------------
 // EXACT: the census weights are exactly summable (the cost is the integer field sum times the unit).  A template
@@ -436,8 +490,10 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
     // reset two iterations before it is used, after the barrier that ends its last readers
     __shared__ uint32_t trange_buf[3][3];   // [slot][min byte, max byte other than 255, some byte is 255]
     // bit-sliced median: 3-bit column counts, [plane][tile row][halo column]
-    constexpr bool BITSLICED = MEDIAN && RAD == 3;
-    __shared__ uint32_t colcnt[BITSLICED ? 3 * FF_TH * BS_CW : 1];
+    constexpr bool BITSLICED = MEDIAN;
+    constexpr int NB1 = bs_bits(K), NB2 = bs_bits(K * K);   // bits of a column count, of a window count
+    constexpr int BS_CW = LW + 2;                            // row pitch of the column-count planes
+    __shared__ uint32_t colcnt[BITSLICED ? NB1 * FF_TH * BS_CW : 1];
 
     const WordT *lw = static_cast<const WordT *>(a.lw);
     const WordT *rw = static_cast<const WordT *>(a.rw);
@@ -704,8 +760,8 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
             const int thi = has255 ? 255 : thi2;
             int med[FF_ROWS_PER_THREAD];
             if (BITSLICED && thi2 - tlo <= 30 && !a.plain_median) {
-                // phase 1: 3-bit counts of the four 7-row column segments under this thread's outputs, for halo
-                // column lx; the six columns beyond 63 are taken by the first lanes of one wavefront
+                // phase 1: counts of the K-row column segments under this thread's outputs, for halo column lx; the
+                // 2 * RAD columns beyond 63 are taken by the first lanes of one wavefront
                 auto column_counts = [&](int c, int qq, auto census_tag) {
                     uint32_t m[NR];
 #pragma unroll
@@ -717,12 +773,11 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                     }
 #pragma unroll
                     for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
-                        uint32_t b0, b1, b2;
-                        bs_count7(m + j, b0, b1, b2);
+                        uint32_t bits[NB1];
+                        bs_sum<K>(m + j, bits);
                         const int o = (qq * FF_ROWS_PER_THREAD + j) * BS_CW + c;
-                        colcnt[o] = b0;
-                        colcnt[FF_TH * BS_CW + o] = b1;
-                        colcnt[2 * FF_TH * BS_CW + o] = b2;
+#pragma unroll
+                        for (int pl = 0; pl < NB1; ++pl) colcnt[pl * FF_TH * BS_CW + o] = bits[pl];
                     }
                 };
                 // (the wavefront that takes the extra columns changes from tile to tile: the first wavefronts of
@@ -737,32 +792,39 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                     if (extra) column_counts(FF_TW + xt % (LW - FF_TW), xt / (LW - FF_TW), std::false_type{});
                 }
                 __syncthreads();
-                // phase 2: add the seven columns of each window, find the first level with count >= 25
+                // phase 2: add the K columns of each window, find the first level with count >= K * K / 2 + 1
 #pragma unroll
                 for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
                     const uint32_t *row = colcnt + (q * FF_ROWS_PER_THREAD + j) * BS_CW + lx;
-                    uint32_t u[3][3];  // u[p]: 3-bit sum of plane p over the 7 columns
+                    uint32_t u[NB1][NB1];  // u[p]: sum of plane p over the K columns
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < NB1; ++pl) {
                         uint32_t m[K];
 #pragma unroll
                         for (int dx = 0; dx < K; ++dx) m[dx] = row[pl * FF_TH * BS_CW + dx];
-                        bs_count7(m, u[pl][0], u[pl][1], u[pl][2]);
+                        bs_sum<K>(m, u[pl]);
                     }
-                    // S = U0 + 2 U1 + 4 U2, bit planes s0 .. s5 (S <= 49)
-                    const uint32_t s0 = u[0][0];
-                    const uint32_t s1 = u[0][1] ^ u[1][0], c2 = u[0][1] & u[1][0];
-                    const uint32_t x4 = bs_xor3(u[0][2], u[1][1], u[2][0]), y4 = bs_maj3(u[0][2], u[1][1], u[2][0]);
-                    const uint32_t s2 = x4 ^ c2, c4 = x4 & c2;
-                    const uint32_t x8 = bs_xor3(u[1][2], u[2][1], y4), y8 = bs_maj3(u[1][2], u[2][1], y4);
-                    const uint32_t s3 = x8 ^ c4, c8 = x8 & c4;
-                    const uint32_t s4 = bs_xor3(u[2][2], y8, c8), s5 = bs_maj3(u[2][2], y8, c8);
-                    // S >= 25 = 16 + 8 + 1
-                    const uint32_t ge = s5 | bs_and3(s4, s3, bs_or3(s2, s1, s0));
-                    const int t = __builtin_ctz(ge);   // bit 31 is always set: all 49 elements are <= level 31
+                    uint32_t ge;
+                    if constexpr (K == 7) {
+                        // S = U0 + 2 U1 + 4 U2, bit planes s0 .. s5 (S <= 49)
+                        const uint32_t s0 = u[0][0];
+                        const uint32_t s1 = u[0][1] ^ u[1][0], c2 = u[0][1] & u[1][0];
+                        const uint32_t x4 = bs_xor3(u[0][2], u[1][1], u[2][0]), y4 = bs_maj3(u[0][2], u[1][1], u[2][0]);
+                        const uint32_t s2 = x4 ^ c2, c4 = x4 & c2;
+                        const uint32_t x8 = bs_xor3(u[1][2], u[2][1], y4), y8 = bs_maj3(u[1][2], u[2][1], y4);
+                        const uint32_t s3 = x8 ^ c4, c8 = x8 & c4;
+                        const uint32_t s4 = bs_xor3(u[2][2], y8, c8), s5 = bs_maj3(u[2][2], y8, c8);
+                        // S >= 25 = 16 + 8 + 1
+                        ge = s5 | bs_and3(s4, s3, bs_or3(s2, s1, s0));
+                    } else {
+                        uint32_t sb[NB2];
+                        bs_weighted_sum<NB1, NB2, 0, 0>(u, nullptr, sb);
+                        ge = bs_at_least<NB2, (K * K) / 2 + 1>(sb);
+                    }
+                    const int t = __builtin_ctz(ge);   // bit 31 is always set: all K * K elements are <= level 31
                     med[j] = t == 31 ? (has255 ? 255 : tlo + 31) : tlo + t;
                 }
-            } else if (BITSLICED) {
+            } else {
                 // Bytes other than 255 more than 30 levels apart.  Census costs never get here (a cost that is
                 // not `large` is at most a tenth of it, so it quantises to 26 or less above the minimum); the
                 // plain bisection below, which re-reads the window from LDS at every step, keeps the kernel
@@ -781,10 +843,6 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                     }
                     med[j] = lo;
                 }
-            } else if (thi - tlo < 32) {
-                median_bisect<K, 6, LW, FF_ROWS_PER_THREAD>(win, tlo, thi, med);
-            } else {
-                median_bisect<K, 10, LW, FF_ROWS_PER_THREAD>(win, tlo, thi, med);
             }
 #pragma unroll
             for (int j = 0; j < FF_ROWS_PER_THREAD; ++j)

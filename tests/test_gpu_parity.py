@@ -750,18 +750,22 @@ def test_non_finite_guide_pixels(oracle, mode):
         assert rel_err(q[~poisoned], layers[7][~poisoned]) <= TOL
 
 
-@pytest.mark.parametrize("wct_radius", [4, 8])
-def test_fused_median_counting_and_bisection_agree(wct_radius):
-    """The fused uint8 median finds each 7 x 7 median by bit-sliced counting; its plain bisection (kept for
-    tiles whose bytes span more than 30 levels, which census costs never produce) must give the same maps.
-    Both are also covered against the oracle by the other median tests (default path)."""
+@pytest.mark.parametrize("wct_radius,median_radius", [(4, 3), (8, 3), (4, 1), (8, 2), (4, 4), (4, 5), (8, 6), (4, 7), (8, 8)])
+def test_fused_median_counting_and_bisection_agree(oracle, wct_radius, median_radius):
+    """The fused uint8 median finds each median by bit-sliced counting (every window size from 3 x 3 to 17 x 17); its
+    plain bisection (kept for tiles whose bytes span more than 30 levels, which census costs never produce) must
+    give the same maps, and both the oracle's."""
     import stereo
     from synth import synth_pair_gray
     left, right, _ = synth_pair_gray(150, 333, 48, seed=21)
-    run = lambda: stereo.compute_disparity(left, right, 48, wct_radius=wct_radius, filter_type="median", show_progress=False)
+    run = lambda: stereo.compute_disparity(left, right, 48, wct_radius=wct_radius, filter_type="median",
+                                           median_radius=median_radius, show_progress=False)
+    dsi = oracle.wct_cost_volume(left, right, 48, radius=wct_radius)
+    dref, cref = oracle.aggregate_and_wta(dsi, left, oracle.FILTER_MEDIAN_U8Q, median_radius, 0.0)
     d0, c0 = _with_kernel(0, run)
     d1, c1 = _with_kernel(1, run)
     assert np.array_equal(d0, d1) and np.array_equal(c0, c1)
+    assert np.array_equal(d0, dref) and np.array_equal(c0, cref)
 
 
 def test_fused_median_rescale_rounds_twice(oracle):
