@@ -67,6 +67,11 @@ int make_census_cfg(int radius, double base_weight, CensusCfg *cfg) {
         exact = (sig_bits + m_bits <= 24);
     }
     cfg->exact = exact;
+    cfg->seq_fma = 1;
+    for (int r = 0; r < 8; ++r) {
+        cfg->hw[r] = cfg->w[r] * 0.5f;
+        if (!std::isfinite(cfg->w[r]) || !(std::fabs(cfg->hw[r]) >= 1.17549435e-38f)) cfg->seq_fma = 0;
+    }
     return STEREO_OK;
 }
 

@@ -104,6 +104,8 @@ struct CensusCfg {
     float unit;      // cost of one unit of the packed integer sum (base/8 or base/128)
     float large;     // census.py:240
     float w[8];      // w[r-1] = float32(base_weight / 2**(r-1))
+    float hw[8];     // w[r-1] / 2 (exact), for the branch-free form of the sequential sum
+    int seq_fma;     // 1: every w is finite and every hw a normal number (the branch-free form applies)
 };
 int make_census_cfg(int radius, double base_weight, CensusCfg *cfg);
 
