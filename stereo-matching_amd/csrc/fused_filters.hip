@@ -37,11 +37,13 @@ constexpr int FF_TW = 64, FF_THREADS = 256;
 #ifndef FF_MEDX_RPT
 #define FF_MEDX_RPT 4
 #endif
-template <int FILTER> struct FFTile {
-    static constexpr int RPT = (FILTER == STEREO_FILTER_MEDIAN_U8Q) ? FF_MEDIAN_RPT : (FILTER == STEREO_FILTER_GAUSSIAN) ? FF_GAUSS_RPT : (FILTER == STEREO_FILTER_MEDIAN) ? FF_MEDX_RPT : 4;
+template <int FILTER, int RAD> struct FFTile {
+    // (uint8 median above radius 8: four rows, so that the cost tiles and the column counts stay within 64 KB of LDS)
+    static constexpr int RPT = (FILTER == STEREO_FILTER_MEDIAN_U8Q) ? (RAD > 8 ? 4 : FF_MEDIAN_RPT) : (FILTER == STEREO_FILTER_GAUSSIAN) ? FF_GAUSS_RPT : (FILTER == STEREO_FILTER_MEDIAN) ? FF_MEDX_RPT : 4;
     static constexpr int TH = 4 * RPT;
 };
-constexpr int FF_MAX_RADIUS = 8;
+constexpr int FF_MAX_RADIUS = 8;          // Gaussian, bilateral, exact median
+constexpr int FF_MAX_MEDIAN_RADIUS = 12;  // uint8 median (bit-sliced counting; no weight tables)
 #ifndef FF_BIL_UNROLL_MAX
 #define FF_BIL_UNROLL_MAX 2
 #endif
@@ -475,7 +477,7 @@ __device__ __forceinline__ uint32_t bs_at_least(const uint32_t *s) {
 template <int FILTER, bool WORD64, int RAD, bool EXACT>
 __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
     using WordT = typename std::conditional<WORD64, uint64_t, uint32_t>::type;
-    constexpr int FF_ROWS_PER_THREAD = FFTile<FILTER>::RPT, FF_TH = FFTile<FILTER>::TH;
+    constexpr int FF_ROWS_PER_THREAD = FFTile<FILTER, RAD>::RPT, FF_TH = FFTile<FILTER, RAD>::TH;
     constexpr int K = 2 * RAD + 1;
     constexpr int LW = FF_TW + 2 * RAD, LH = FF_TH + 2 * RAD, NP = LW * LH;
     constexpr int PT = (NP + FF_THREADS - 1) / FF_THREADS;   // halo pixels per thread
@@ -494,6 +496,8 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
     constexpr int NB1 = bs_bits(K), NB2 = bs_bits(K * K);   // bits of a column count, of a window count
     constexpr int BS_CW = LW + 2;                            // row pitch of the column-count planes
     __shared__ uint32_t colcnt[BITSLICED ? NB1 * FF_TH * BS_CW : 1];
+    static_assert(sizeof(float) * 2 * NP + sizeof(uint32_t) * (BITSLICED ? NB1 * FF_TH * BS_CW : 1) + 64 <= 64 * 1024,
+                  "the cost tiles and the column counts must fit the 64 KB of static LDS");
 
     const WordT *lw = static_cast<const WordT *>(a.lw);
     const WordT *rw = static_cast<const WordT *>(a.rw);
@@ -782,8 +786,9 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                 };
                 // (the wavefront that takes the extra columns changes from tile to tile: the first wavefronts of
                 //  the workgroups that share a compute unit would otherwise all load the same SIMD)
-                const int xt = tid - 64 * (int)((blockIdx.x + blockIdx.y) & 3u);
-                const bool extra = xt >= 0 && xt < 4 * (LW - FF_TW);
+                const int xt = (tid - 64 * (int)((blockIdx.x + blockIdx.y) & 3u)) & (FF_THREADS - 1);
+                const bool extra = xt < 4 * (LW - FF_TW);   // (8 * RAD jobs: one wavefront up to radius 8, two above)
+                static_assert(4 * (LW - FF_TW) <= 128, "the extra columns are dealt to at most two wavefronts");
                 if (census_levels) {
                     column_counts(lx, q, std::true_type{});
                     if (extra) column_counts(FF_TW + xt % (LW - FF_TW), xt / (LW - FF_TW), std::true_type{});
@@ -868,14 +873,14 @@ bool fused_filter_supported(int filter_kind, int radius) {
     // (the exact median in addition needs exactly summable census weights: launch_fused_filter refuses the others)
     return (filter_kind == STEREO_FILTER_MEDIAN_U8Q || filter_kind == STEREO_FILTER_GAUSSIAN ||
             filter_kind == STEREO_FILTER_BILATERAL || filter_kind == STEREO_FILTER_MEDIAN) &&
-           radius >= 1 && radius <= FF_MAX_RADIUS;
+           radius >= 1 && radius <= (filter_kind == STEREO_FILTER_MEDIAN_U8Q ? FF_MAX_MEDIAN_RADIUS : FF_MAX_RADIUS);
 }
 
 size_t fused_filter_minmax_bytes(int n_disp) { return (size_t)n_disp * 8; }
 
 template <int FILTER, bool WORD64, int RAD>
 static int launch_ff(const FFArgs &a, hipStream_t s) {
-    dim3 grid(ceil_div(a.W, FF_TW), ceil_div(a.H, FFTile<FILTER>::TH));
+    dim3 grid(ceil_div(a.W, FF_TW), ceil_div(a.H, FFTile<FILTER, RAD>::TH));
     // (the exact median works on integer codes: it has one form only)
     if (a.cfg.exact && a.cfg.unit > 0.f && FILTER != STEREO_FILTER_MEDIAN)
         hipLaunchKernelGGL((fused_filter_kernel<FILTER, WORD64, RAD, true>), grid, dim3(FF_THREADS), 0, s, a);
@@ -895,8 +900,19 @@ static int launch_ff_r(const FFArgs &a, int radius, hipStream_t s) {
         case 6: return launch_ff<FILTER, WORD64, 6>(a, s);
         case 7: return launch_ff<FILTER, WORD64, 7>(a, s);
         case 8: return launch_ff<FILTER, WORD64, 8>(a, s);
-        default: set_error("fused filter kernels support radius 1..%d", FF_MAX_RADIUS); return STEREO_EUNSUPPORTED;
+        default: break;
     }
+    if constexpr (FILTER == STEREO_FILTER_MEDIAN_U8Q) {
+        switch (radius) {
+            case 9: return launch_ff<FILTER, WORD64, 9>(a, s);
+            case 10: return launch_ff<FILTER, WORD64, 10>(a, s);
+            case 11: return launch_ff<FILTER, WORD64, 11>(a, s);
+            case 12: return launch_ff<FILTER, WORD64, 12>(a, s);
+            default: break;
+        }
+    }
+    set_error("fused filter kernels support radius 1..%d (uint8 median: 1..%d)", FF_MAX_RADIUS, FF_MAX_MEDIAN_RADIUS);
+    return STEREO_EUNSUPPORTED;
 }
 template <int FILTER>
 static int launch_ff_w(const FFArgs &a, int radius, hipStream_t s) {

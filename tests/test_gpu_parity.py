@@ -588,8 +588,10 @@ def test_equal_negative_costs_keep_the_lower_disparity(rg):
     ("median", {"median_radius": 1}, "FILTER_MEDIAN_U8Q", 1, 0.0, 0.999),
     ("median", {"median_radius": 4}, "FILTER_MEDIAN_U8Q", 4, 0.0, 0.999),
     ("median", {"median_radius": 6}, "FILTER_MEDIAN_U8Q", 6, 0.0, 0.999),
-    ("median", {"median_radius": 8}, "FILTER_MEDIAN_U8Q", 8, 0.0, 0.999),          # the largest fused one
-    ("median", {"median_radius": 9}, "FILTER_MEDIAN_U8Q", 9, 0.0, 0.999),          # layer-at-a-time path
+    ("median", {"median_radius": 8}, "FILTER_MEDIAN_U8Q", 8, 0.0, 0.999),
+    ("median", {"median_radius": 9}, "FILTER_MEDIAN_U8Q", 9, 0.0, 0.999),
+    ("median", {"median_radius": 12}, "FILTER_MEDIAN_U8Q", 12, 0.0, 0.999),        # the largest fused one
+    ("median", {"median_radius": 13}, "FILTER_MEDIAN_U8Q", 13, 0.0, 0.999),        # layer-at-a-time path
     # exact float32 median (scipy / vectorized / naive): fused on integer cost codes, bit-exact
     ("median", {"median_radius": 1, "median_method": "scipy"}, "FILTER_MEDIAN", 1, 0.0, 1.0),
     ("median", {"median_radius": 3, "median_method": "vectorized"}, "FILTER_MEDIAN", 3, 0.0, 1.0),
@@ -750,9 +752,10 @@ def test_non_finite_guide_pixels(oracle, mode):
         assert rel_err(q[~poisoned], layers[7][~poisoned]) <= TOL
 
 
-@pytest.mark.parametrize("wct_radius,median_radius", [(4, 3), (8, 3), (4, 1), (8, 2), (4, 4), (4, 5), (8, 6), (4, 7), (8, 8)])
+@pytest.mark.parametrize("wct_radius,median_radius", [(4, 3), (8, 3), (4, 1), (8, 2), (4, 4), (4, 5), (8, 6), (4, 7), (8, 8),
+                                                      (4, 9), (8, 10), (4, 11), (8, 12)])
 def test_fused_median_counting_and_bisection_agree(oracle, wct_radius, median_radius):
-    """The fused uint8 median finds each median by bit-sliced counting (every window size from 3 x 3 to 17 x 17); its
+    """The fused uint8 median finds each median by bit-sliced counting (every window size from 3 x 3 to 25 x 25); its
     plain bisection (kept for tiles whose bytes span more than 30 levels, which census costs never produce) must
     give the same maps, and both the oracle's."""
     import stereo
