@@ -116,9 +116,9 @@ int stereo_aggregate_wta_host(const float *dsi, const void *guide, int guide_dty
                               int dmax, const StereoParams *params, int d_begin, int d_end,
                               int32_t *out_disparity, float *out_min_cost);
 /* compute_disparity (stereo.py:177-245).  float32 / uint8 images take a fused kernel -- the cost volume is never
- * materialised -- for the guided filter (radius 1..8), the uint8-quantised median (radius 1..12), the Gaussian and
- * the bilateral filter (window radius 1..8) and, for census weights whose sums are exact in float32, the exact
- * median (radius 1..8).  Other combinations (float64 images, larger windows, the exact median with other weights) build
+ * materialised -- for the guided filter (radius 1..8), the uint8-quantised median, the Gaussian and the bilateral
+ * filter (window radius 1..12) and, for census weights whose sums are exact in float32, the exact median
+ * (radius 1..8).  Other combinations (float64 images, larger windows, the exact median with other weights) build
  * the cost layers on the device and filter them one at a time.  Disparities d in [d_begin, d_end) are searched. */
 int stereo_compute_disparity_host(const void *left, const void *right, int dtype, int height, int width,
                                   int dmax, const StereoParams *params, int d_begin, int d_end,
@@ -146,7 +146,7 @@ int stereo_fused_workspace_bytes(int height, int width, const StereoParams *para
  * "lowest cost, ties to the lowest disparity" rule (stereo.py:167-170).
  * Covers the guided filter (radius 1..8), the uint8-quantised median (radius 1..12), the exact median
  * (radius 1..8, census weights whose sums are exact in float32) and the Gaussian / bilateral filters
- * (max(ceil(3 sigma), 1) <= 8); other parameters return STEREO_EUNSUPPORTED (the host entry point falls back to
+ * (max(ceil(3 sigma), 1) <= 12); other parameters return STEREO_EUNSUPPORTED (the host entry point falls back to
  * the layer-at-a-time path for them). */
 int stereo_compute_disparity_dev(const float *d_left, const float *d_right, int height, int width, int dmax,
                                  const StereoParams *params, int d_begin, int d_end, void *d_workspace,

@@ -13,6 +13,7 @@
 // before any pixel of the layer can be quantised: cost_minmax_kernel computes them for every
 // disparity of the launch from the census words in a first pass.
 #include <type_traits>
+#include <vector>
 
 #include "census_dev.hpp"
 
@@ -42,8 +43,10 @@ template <int FILTER, int RAD> struct FFTile {
     static constexpr int RPT = (FILTER == STEREO_FILTER_MEDIAN_U8Q) ? (RAD > 8 ? 4 : FF_MEDIAN_RPT) : (FILTER == STEREO_FILTER_GAUSSIAN) ? FF_GAUSS_RPT : (FILTER == STEREO_FILTER_MEDIAN) ? FF_MEDX_RPT : 4;
     static constexpr int TH = 4 * RPT;
 };
-constexpr int FF_MAX_RADIUS = 8;          // Gaussian, bilateral, exact median
+constexpr int FF_MAX_RADIUS = 8;          // bilateral (2-D weight tables in the kernel arguments), exact median
 constexpr int FF_MAX_MEDIAN_RADIUS = 12;  // uint8 median (bit-sliced counting; no weight tables)
+constexpr int FF_MAX_GAUSS_RADIUS = 12;   // Gaussian (separable: a 1-D weight table)
+constexpr int FF_MAX_BIL_RADIUS = 12;     // bilateral above FF_MAX_RADIUS: the 2-D table of log2 weights is formed in LDS from a 1-D one
 #ifndef FF_BIL_UNROLL_MAX
 #define FF_BIL_UNROLL_MAX 2
 #endif
@@ -53,11 +56,13 @@ struct FFArgs {
     CensusCfg cfg;
     int H, W, d_begin, d_end;
     float kern[(2 * FF_MAX_RADIUS + 1) * (2 * FF_MAX_RADIUS + 1)];  // normalised spatial weights, row-major
-    float kern1[2 * FF_MAX_RADIUS + 1];  // Gaussian: normalised 1-D weights
+    float kern1[2 * FF_MAX_GAUSS_RADIUS + 1];  // Gaussian: normalised 1-D weights
     // bilateral: log2 of the spatial weights, rows padded to an even length so that a pair of horizontally adjacent
     // weights is one aligned 8-byte scalar load
     alignas(8) float kernp[2 * FF_MAX_RADIUS + 1][2 * FF_MAX_RADIUS + 2];
     float vscale, inv_vscale;   // bilateral: sqrt(log2(e) / (2 sigma^2)) and its reciprocal
+    // bilateral, radius above FF_MAX_RADIUS: log2 of the spatial weight of (dy, dx) = kern_lg1[dy] + kern_lg1[dx]
+    float kern_lg1[2 * FF_MAX_BIL_RADIUS + 1];
     uint32_t *mm;         // median: [d - d_begin][2] order-preserving (min, max) of the cost layer
     uint64_t *keys;
     int plain_median;     // test hook: take the plain bisection instead of the bit-sliced count
@@ -504,6 +509,15 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
     const int H = a.H, W = a.W, R = a.cfg.radius;
     const int x0 = blockIdx.x * FF_TW, y0 = blockIdx.y * FF_TH;
     const int tid = threadIdx.x;
+    // bilateral windows too large for a table in the kernel arguments: log2 of the spatial weights, rows padded to an
+    // even length, summed from the 1-D table (the first barrier of the disparity loop orders these writes)
+    constexpr bool BIL_LDS_TABLE = FILTER == STEREO_FILTER_BILATERAL && RAD > FF_MAX_RADIUS;
+    __shared__ __attribute__((aligned(8))) float lgtab[BIL_LDS_TABLE ? K * (K + 1) : 2];
+    if (BIL_LDS_TABLE)
+        for (int i = tid; i < K * (K + 1); i += FF_THREADS) {
+            const int dy = i / (K + 1), dx = i - dy * (K + 1);
+            lgtab[i] = dx < K ? a.kern_lg1[dy] + a.kern_lg1[dx] : 0.f;
+        }
 
     // this thread's pixels of the tile + halo, with the filter's border rule applied
     WordT lword[PT];
@@ -730,7 +744,8 @@ __global__ __launch_bounds__(FF_THREADS) void fused_filter_kernel(FFArgs a) {
                     for (int j = 0; j < FF_ROWS_PER_THREAD; ++j) {
                         const int dy = rr - j;
                         if (dy >= 0 && dy < K) {
-                            const float *kr = a.kernp[dy];
+                            const float *kr;
+                            if constexpr (BIL_LDS_TABLE) kr = &lgtab[dy * (K + 1)]; else kr = a.kernp[dy];
                             const fpair cc = fpair{c[j], c[j]};
 #pragma unroll
                             for (int dx = 0; dx + 1 < K; dx += 2) {
@@ -873,7 +888,9 @@ bool fused_filter_supported(int filter_kind, int radius) {
     // (the exact median in addition needs exactly summable census weights: launch_fused_filter refuses the others)
     return (filter_kind == STEREO_FILTER_MEDIAN_U8Q || filter_kind == STEREO_FILTER_GAUSSIAN ||
             filter_kind == STEREO_FILTER_BILATERAL || filter_kind == STEREO_FILTER_MEDIAN) &&
-           radius >= 1 && radius <= (filter_kind == STEREO_FILTER_MEDIAN_U8Q ? FF_MAX_MEDIAN_RADIUS : FF_MAX_RADIUS);
+           radius >= 1 && radius <= (filter_kind == STEREO_FILTER_MEDIAN_U8Q ? FF_MAX_MEDIAN_RADIUS :
+                                     filter_kind == STEREO_FILTER_GAUSSIAN ? FF_MAX_GAUSS_RADIUS :
+                                     filter_kind == STEREO_FILTER_BILATERAL ? FF_MAX_BIL_RADIUS : FF_MAX_RADIUS);
 }
 
 size_t fused_filter_minmax_bytes(int n_disp) { return (size_t)n_disp * 8; }
@@ -902,7 +919,7 @@ static int launch_ff_r(const FFArgs &a, int radius, hipStream_t s) {
         case 8: return launch_ff<FILTER, WORD64, 8>(a, s);
         default: break;
     }
-    if constexpr (FILTER == STEREO_FILTER_MEDIAN_U8Q) {
+    if constexpr (FILTER == STEREO_FILTER_MEDIAN_U8Q || FILTER == STEREO_FILTER_GAUSSIAN || FILTER == STEREO_FILTER_BILATERAL) {
         switch (radius) {
             case 9: return launch_ff<FILTER, WORD64, 9>(a, s);
             case 10: return launch_ff<FILTER, WORD64, 10>(a, s);
@@ -911,7 +928,7 @@ static int launch_ff_r(const FFArgs &a, int radius, hipStream_t s) {
             default: break;
         }
     }
-    set_error("fused filter kernels support radius 1..%d (uint8 median: 1..%d)", FF_MAX_RADIUS, FF_MAX_MEDIAN_RADIUS);
+    set_error("fused filter kernels support radius 1..%d (exact median: 1..%d)", FF_MAX_MEDIAN_RADIUS, FF_MAX_RADIUS);
     return STEREO_EUNSUPPORTED;
 }
 template <int FILTER>
@@ -939,11 +956,10 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
         return launch_ff_w<STEREO_FILTER_MEDIAN>(a, radius, s);
     }
     if (filter_kind != STEREO_FILTER_MEDIAN_U8Q) {
-        gaussian_kernel_host(radius, sigma, a.kern);
         if (filter_kind == STEREO_FILTER_GAUSSIAN) {
             // float32 exponentials as the reference forms them, normalised in float64
             const float denom32 = (float)(2.0 * sigma * sigma);
-            double e[2 * FF_MAX_RADIUS + 1], sum = 0.0;
+            double e[2 * FF_MAX_GAUSS_RADIUS + 1], sum = 0.0;
             for (int t = -radius; t <= radius; ++t) {
                 const float ft = (float)t;
                 e[t + radius] = (double)std::exp(-(ft * ft) / denom32);
@@ -951,11 +967,23 @@ int launch_fused_filter(const void *d_lw, const void *d_rw, const CensusCfg &cfg
             }
             for (int t = 0; t <= 2 * radius; ++t) a.kern1[t] = (float)(e[t] / sum);
         }
-        if (filter_kind == STEREO_FILTER_BILATERAL) {
+        if (filter_kind == STEREO_FILTER_BILATERAL && radius > FF_MAX_RADIUS) {
+            // the reference's normalised float32 table (filters.py:24-39) is exp(-dy^2/2s^2) exp(-dx^2/2s^2) / sum up to
+            // the rounding of its float32 exponentials: log2 k(dy, dx) = lg1[dy] + lg1[dx] with
+            // lg1[t] = log2 k(t, centre) - log2 k(centre, centre) / 2, to about 1e-7 of the weight
+            const int size = 2 * radius + 1;
+            std::vector<float> k2(size * size);
+            gaussian_kernel_host(radius, sigma, k2.data());
+            const double half_centre = 0.5 * std::log2((double)k2[radius * size + radius]);
+            for (int t = 0; t < size; ++t) a.kern_lg1[t] = (float)(std::log2((double)k2[t * size + radius]) - half_centre);
+        } else if (filter_kind == STEREO_FILTER_BILATERAL) {
+            gaussian_kernel_host(radius, sigma, a.kern);
             const int kk = (2 * radius + 1) * (2 * radius + 1);
             for (int i = 0; i < kk; ++i) a.kern[i] = (float)std::log2((double)a.kern[i]);
             for (int y = 0; y <= 2 * radius; ++y)
                 for (int x = 0; x <= 2 * radius; ++x) a.kernp[y][x] = a.kern[y * (2 * radius + 1) + x];
+        }
+        if (filter_kind == STEREO_FILTER_BILATERAL) {
             const double denom = (double)(float)(2.0 * (sigma * sigma));   // the reference's float32 denominator
             a.vscale = (float)std::sqrt(1.4426950408889634 / denom);
             a.inv_vscale = (float)(1.0 / (double)a.vscale);

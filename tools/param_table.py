@@ -33,6 +33,8 @@ CASES = [
     ("gaussian sigma=2 (radius 6)", dict(filter_type="gaussian", gaussian_sigma=2.0)),
     ("bilateral sigma=1", dict(filter_type="bilateral")),
     ("bilateral sigma=2 (radius 6)", dict(filter_type="bilateral", bilateral_sigma=2.0)),
+    ("gaussian sigma=3 (radius 9)", dict(filter_type="gaussian", gaussian_sigma=3.0)),
+    ("bilateral sigma=3 (radius 9)", dict(filter_type="bilateral", bilateral_sigma=3.0)),
     ("median r=9 opencv", dict(filter_type="median", median_radius=9)),
     ("median r=13 opencv (no fused kernel)", dict(filter_type="median", median_radius=13)),
 ]
